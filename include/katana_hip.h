@@ -1,0 +1,243 @@
+/* katana_hip.h -- C ABI of the MI355X-native Extended-Cutting-Plane engine.
+ *
+ * Drop-in boundary for the ONE hot path of lanl-ansi/Katana.jl:
+ * the MathProgBase / KatanaSolver plugin surface and the separator API, re-expressed
+ * as plain C so that a Julia `ccall` shim, the Python ctypes host
+ * mirror (katana.jl_amd/solver.py) or any other FFI can bind it.  No torch types,
+ * no C++ types: plain pointers and sizes.  All indices are 0-based.
+ *
+ * Every entry point names the reference interface it replaces (file:line relative
+ * to the reference tree).  Functions return 0 on success and a negative KTN_E_* code
+ * on failure (never throw, never abort); ktn_last_error() gives the message.
+ * Host buffers are copied at the call (caller keeps ownership); the library owns all
+ * device memory until ktn_destroy.  One handle <-> one host thread at a time; every
+ * handle owns its HIP stream.  The library REQUIRES a gfx950 device: there is no CPU
+ * fallback, ktn_create fails with KTN_E_NODEVICE when none is visible.
+ */
+#ifndef KATANA_HIP_H
+#define KATANA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KTN_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------------ */
+#define KTN_OK            0
+#define KTN_E_INVALID    -1   /* bad argument / call order                          */
+#define KTN_E_NODEVICE   -2   /* no HIP device (the product has no CPU path)        */
+#define KTN_E_HIP        -3   /* a HIP runtime call failed                           */
+#define KTN_E_NOMEM      -4
+#define KTN_E_UNSUPPORTED -5  /* e.g. unknown tape opcode ("Unsupported feature",
+                                 src/nlpeval.jl:28)                                  */
+#define KTN_E_EXCHANGE   -6   /* the multi-GPU exchange callback failed              */
+
+/* ---- status vocabulary: MathProgBase.status(m) symbols ------------------------
+ * :None src/model.jl:44, :Optimal, :Unbounded :246, LP pass-through e.g. :Infeasible
+ * :261-263, :UserLimit :314, :Error :71 */
+#define KTN_STATUS_NONE       0
+#define KTN_STATUS_OPTIMAL    1
+#define KTN_STATUS_UNBOUNDED  2
+#define KTN_STATUS_INFEASIBLE 3
+#define KTN_STATUS_USERLIMIT  4
+#define KTN_STATUS_ERROR      5
+
+#define KTN_MIN 0   /* sense :Min */
+#define KTN_MAX 1   /* sense :Max */
+
+/* ---- how a constraint row (or the objective) is evaluated on the device --------
+ * Replaces the closures behind MathProgBase.eval_g / eval_jac_g / eval_f /
+ * eval_grad_f (call sites src/separators.jl:112-113, src/nlpeval.jl:35-63). */
+#define KTN_ROW_SEP  0   /* separable: g_i(x) = sum_e atom_e(x[col_e]) + rconst_i    */
+#define KTN_ROW_TAPE 1   /* general: postfix expression tape, reverse-mode AD        */
+
+/* separable atoms, two f64 parameters per Jacobian entry */
+#define KTN_ATOM_LIN    0   /* p0 * x                */
+#define KTN_ATOM_QUAD   1   /* p0 * (x - p1)^2       */
+#define KTN_ATOM_EXP    2   /* p0 * exp(p1 * x)      */
+#define KTN_ATOM_NEGLOG 3   /* -p0 * log(x + p1)     */
+
+/* postfix tape opcodes; `arg` is the constant for CONST/POWC and the 0-based
+ * variable index (stored as a double) for VAR */
+#define KTN_OP_CONST 0
+#define KTN_OP_VAR   1
+#define KTN_OP_ADD   2
+#define KTN_OP_SUB   3
+#define KTN_OP_MUL   4
+#define KTN_OP_DIV   5
+#define KTN_OP_NEG   6
+#define KTN_OP_POWC  7   /* x ^ arg, arg constant */
+#define KTN_OP_EXP   8
+#define KTN_OP_LOG   9
+#define KTN_OP_SQRT  10
+#define KTN_OP_SIN   11
+#define KTN_OP_COS   12
+
+typedef struct ktn_handle_s* ktn_handle;
+
+/* KatanaSolver keyword arguments and defaults, src/solver.jl:34-43 +
+ * KatanaModelParams src/Katana.jl:12-19.  `lp_solver` has no counterpart: the LP is
+ * solved on the GPU by the built-in first-order method; the lp_* fields tune it. */
+typedef struct {
+    double  f_tol;          /* 1e-6   feasibility tolerance                         */
+    double  cut_coef_rng;   /* 1e9    max coefficient range per cut                 */
+    int32_t log_level;      /* 10     print every log_level iterations, 0 = silent  */
+    int32_t iter_cap;       /* 10000  iteration cap                                 */
+    double  obj_eps;        /* -1.0   objective-delta stop (disabled when < 0)      */
+    int32_t vis_data;       /* 0      feature :VisData (src/model.jl:1-4,29-31)     */
+    int32_t device;         /* -1     HIP device ordinal; -1 = current device       */
+    /* GPU LP (restarted reflected Halpern PDHG) */
+    int32_t lp_max_iter;    /* 2000000 PDHG iterations per LP solve                 */
+    int32_t lp_check_every; /* 64      iterations between KKT checks                */
+    int32_t lp_ruiz_iters;  /* 10                                                   */
+    double  lp_tol_scale;   /* 0.1     LP row tolerance = lp_tol_scale * max viol.  */
+    double  lp_tol_floor;   /* 0.3     ... floored at lp_tol_floor * f_tol          */
+    double  lp_tol_cap;     /* 1e-3    ... capped                                   */
+    double  lp_gap_floor;   /* 1e-7    relative duality-gap tolerance floor         */
+    double  lp_gap_cap;     /* 1e-4                                                 */
+    int32_t lp_dual_inherit;/* 1       new cut of NL row i inherits the dual of its
+                                       previous cut (warm start)                    */
+    int32_t profile;        /* 0       per-launch hipEvent timing of the hot kernels */
+} ktn_params;
+
+/* The device-evaluable statement of the NLP: replaces the
+ * MathProgBase.AbstractNLPEvaluator `d` handed to loadproblem! (src/model.jl:86).
+ * Jacobian structure is CSR over the num_constr constraints (what initialize! builds
+ * from jac_structure, src/separators.jl:92-104). */
+typedef struct {
+    int64_t num_var;
+    int64_t num_constr;
+    /* Jacobian structure */
+    const int64_t* rowptr;      /* [num_constr+1]                                    */
+    const int32_t* col;         /* [nnz]                                             */
+    /* per row */
+    const uint8_t* row_kind;    /* [num_constr] KTN_ROW_*                            */
+    const uint8_t* row_linear;  /* [num_constr] isconstrlinear(d,i), src/model.jl:116 */
+    const double*  rconst;      /* [num_constr] constant of separable rows           */
+    /* separable atoms, per Jacobian entry (unused entries of tape rows ignored)     */
+    const uint8_t* atom_kind;   /* [nnz] KTN_ATOM_*                                  */
+    const double*  p0;          /* [nnz]                                             */
+    const double*  p1;          /* [nnz]                                             */
+    /* tapes: row i owns ops [tape_ptr[i], tape_ptr[i+1]) (empty for separable rows) */
+    const int64_t* tape_ptr;    /* [num_constr+1] or NULL when there are no tapes    */
+    const int32_t* tape_op;
+    const double*  tape_arg;
+    /* objective f(x): isobjlinear src/model.jl:125; same two forms                  */
+    int32_t obj_linear;
+    int32_t obj_kind;           /* KTN_ROW_SEP or KTN_ROW_TAPE                       */
+    int64_t obj_nnz;            /* separable objective entries                       */
+    const int32_t* obj_col;
+    const uint8_t* obj_atom_kind;
+    const double*  obj_p0;
+    const double*  obj_p1;
+    double         obj_const;
+    int64_t        obj_tape_len;
+    const int32_t* obj_tape_op;
+    const double*  obj_tape_arg;
+} ktn_nlp_desc;
+
+/* ---- plugin surface -------------------------------------------------------------- */
+
+/* defaults of KatanaSolver(...) src/solver.jl:34-43 */
+void ktn_default_params(ktn_params* p);
+
+/* KatanaSolver(lp_solver; kwargs) + MathProgBase.NonlinearModel(s)
+ * (src/solver.jl:34-43, src/model.jl:41-65) */
+int ktn_create(const ktn_params* p, ktn_handle* out);
+void ktn_destroy(ktn_handle h);
+const char* ktn_last_error(ktn_handle h);
+int ktn_abi_version(void);
+
+/* MathProgBase.loadproblem!(m, num_var, num_constr, l_var, u_var, l_constr, u_constr,
+ * sense, d)  src/model.jl:81-173 */
+int ktn_loadproblem(ktn_handle h, int64_t num_var, int64_t num_constr,
+                    const double* l_var, const double* u_var,
+                    const double* l_constr, const double* u_constr,
+                    int32_t sense, const ktn_nlp_desc* d);
+
+/* MathProgBase.optimize!(m)  src/model.jl:219-319; returns the status code (>= 0)
+ * or a negative error */
+int ktn_optimize(ktn_handle h);
+
+/* one pass of the hot loop src/model.jl:258-308 (LP re-solve -> sweep -> cuts);
+ * *done = 1 when the loop condition of :257 ends.  ktn_optimize == presolve + steps. */
+int ktn_optimize_begin(ktn_handle h);           /* src/model.jl:227-256 (presolve)   */
+int ktn_ecp_step(ktn_handle h, int32_t* done);
+int ktn_optimize_end(ktn_handle h);             /* src/model.jl:311-318              */
+/* forget all cuts and iterates: back to the state right after ktn_loadproblem */
+int ktn_reset(ktn_handle h);
+
+/* MathProgBase.status / getobjval / getsolution / getsolvetime  src/model.jl:337-343;
+ * numiters / numcuts src/model.jl:326,333; setwarmstart! (a no-op) :335 */
+int     ktn_get_status(ktn_handle h);
+double  ktn_get_objval(ktn_handle h);
+int64_t ktn_get_num_var(ktn_handle h);     /* incl. the epigraph variable, model.jl:138 */
+int     ktn_get_solution(ktn_handle h, double* x_out, int64_t n);
+double  ktn_get_solvetime(ktn_handle h);
+int64_t ktn_numiters(ktn_handle h);
+int64_t ktn_numcuts(ktn_handle h);
+int     ktn_setwarmstart(ktn_handle h, const double* x, int64_t n);
+
+/* ---- separator API (batched form of src/separators.jl:23-53,111-120) --------------
+ * precompute!(sep, xstar): evaluate g and the sparse Jacobian of ALL rows of the
+ * loaded (epigraph-lifted) problem at xstar [num_var incl. aux] on the device. */
+int ktn_sep_precompute(ktn_handle h, const double* xstar, int64_t n);
+int64_t ktn_sep_num_constr(ktn_handle h);  /* incl. the epigraph row                  */
+int64_t ktn_sep_jac_nnz(ktn_handle h);
+int ktn_sep_get_g(ktn_handle h, double* g_out, int64_t m);
+int ktn_sep_get_jac(ktn_handle h, double* jac_out, int64_t nnz);
+int ktn_sep_get_structure(ktn_handle h, int64_t* rowptr_out, int32_t* col_out);
+/* isconstrsat(sep, i, lb, ub, f_tol) src/separators.jl:120 -> 1/0 */
+int ktn_sep_isconstrsat(ktn_handle h, int64_t i, double lb, double ub, double f_tol);
+/* gencut(sep, xstar, bounds, i) -> AffExpr  src/separators.jl:118 +
+ * linear_oa_cut src/algorithms.jl:3-18; *nnz in: capacity, out: entries written */
+int ktn_sep_gencut(ktn_handle h, int64_t i, int32_t* cols, double* coefs, int64_t* nnz,
+                   double* constant);
+/* {isconstrsat, gencut, round_coefs, _addcut} over all NL rows at the point of the last
+ * precompute (src/model.jl:272-283, 200-207, 68-79): appends the cuts to the LP.
+ * Outputs: number of violated rows, largest violation. */
+int ktn_sep_sweep(ktn_handle h, double f_tol, int64_t* nviol, double* maxviol);
+
+/* ---- LP introspection: getKatanaCuts / getKatanaSols, src/util.jl:16-36 ------------ */
+int64_t ktn_lp_num_rows(ktn_handle h);
+int64_t ktn_lp_nnz(ktn_handle h);
+int ktn_lp_get_rows(ktn_handle h, int64_t* rowptr, int32_t* col, double* val,
+                    double* lo, double* hi);
+int ktn_lp_get_objective(ktn_handle h, double* c_out, int64_t n, double* c0);
+int ktn_lp_get_duals(ktn_handle h, double* y_out, int64_t m);
+/* solve the current LP to the given tolerances (tests / tools):
+ * row_tol = max unscaled row violation, gap_tol = relative duality gap */
+int ktn_lp_solve(ktn_handle h, double row_tol, double gap_tol, int32_t* lp_status,
+                 int64_t* pdhg_iters);
+/* exactly `iters` PDHG iterations from (x0, y0) with fixed eta/omega, no restart, no
+ * rescaling (dr = dc = 1): kernel-level parity hook for tests */
+int ktn_lp_pdhg_raw(ktn_handle h, const double* x0, const double* y0, double eta,
+                    double omega, int64_t iters, double* x_out, double* y_out);
+int64_t ktn_num_lp_sols(ktn_handle h);           /* :VisData lp_sols, src/model.jl:267 */
+int ktn_get_lp_sol(ktn_handle h, int64_t k, double* x_out, int64_t n);
+
+/* ---- statistics (not in the reference: measurement hooks) ----
+ * names: "lp_time_s" "sep_time_s" "pdhg_iters" "lp_solves" "lp_restarts" "sweeps"
+ *        "kx_time_s" "kx_launches" "kx_bytes" "ky_time_s" "ky_launches" "ky_bytes"
+ *        "sweep_eval_time_s" "sweep_eval_launches" "sweep_eval_bytes" */
+double ktn_get_stat(ktn_handle h, const char* name);
+
+/* ---- multi-GPU: row-block sharding of the NL rows + exchange of generated cuts -----
+ * (no reference counterpart).  rank r owns NL rows
+ * [r*m_nl/world, (r+1)*m_nl/world).  After every sweep the library packs the local cuts
+ * into `send` and calls `xchg`; the callback (RCCL all-gather through torch.distributed
+ * in the Python host) must fill `recv` with every rank's block in rank order and
+ * `recv_counts[2*r] = rows, [2*r+1] = nnz` of rank r.  Buffers are device pointers. */
+typedef int (*ktn_exchange_fn)(void* user, const void* send, int64_t send_bytes,
+                               void* recv, int64_t recv_bytes_per_rank,
+                               int64_t* recv_counts, const int64_t* my_counts);
+int ktn_set_shard(ktn_handle h, int32_t rank, int32_t world);
+int ktn_set_exchange(ktn_handle h, ktn_exchange_fn fn, void* user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KATANA_HIP_H */

@@ -1,0 +1,116 @@
+"""ctypes binding of libkatana_hip.so (the C ABI of include/katana_hip.h)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkatana_hip.so")
+
+KTN_OK = 0
+E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_EXCHANGE = -1, -2, -3, -4, -5, -6
+STATUS_NONE, STATUS_OPTIMAL, STATUS_UNBOUNDED, STATUS_INFEASIBLE, STATUS_USERLIMIT, STATUS_ERROR = range(6)
+MIN, MAX = 0, 1
+ROW_SEP, ROW_TAPE = 0, 1
+ATOM_LIN, ATOM_QUAD, ATOM_EXP, ATOM_NEGLOG = 0, 1, 2, 3
+(OP_CONST, OP_VAR, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_POWC, OP_EXP, OP_LOG, OP_SQRT, OP_SIN,
+ OP_COS) = range(13)
+
+c_i64, c_i32, c_f64, c_u8 = C.c_int64, C.c_int32, C.c_double, C.c_uint8
+P = C.POINTER
+
+
+class KtnParams(C.Structure):
+    _fields_ = [("f_tol", c_f64), ("cut_coef_rng", c_f64), ("log_level", c_i32), ("iter_cap", c_i32),
+                ("obj_eps", c_f64), ("vis_data", c_i32), ("device", c_i32), ("lp_max_iter", c_i32),
+                ("lp_check_every", c_i32), ("lp_ruiz_iters", c_i32), ("lp_tol_scale", c_f64),
+                ("lp_tol_floor", c_f64), ("lp_tol_cap", c_f64), ("lp_gap_floor", c_f64), ("lp_gap_cap", c_f64),
+                ("lp_dual_inherit", c_i32), ("profile", c_i32)]
+
+
+class KtnNlpDesc(C.Structure):
+    _fields_ = [("num_var", c_i64), ("num_constr", c_i64), ("rowptr", P(c_i64)), ("col", P(c_i32)),
+                ("row_kind", P(c_u8)), ("row_linear", P(c_u8)), ("rconst", P(c_f64)), ("atom_kind", P(c_u8)),
+                ("p0", P(c_f64)), ("p1", P(c_f64)), ("tape_ptr", P(c_i64)), ("tape_op", P(c_i32)),
+                ("tape_arg", P(c_f64)), ("obj_linear", c_i32), ("obj_kind", c_i32), ("obj_nnz", c_i64),
+                ("obj_col", P(c_i32)), ("obj_atom_kind", P(c_u8)), ("obj_p0", P(c_f64)), ("obj_p1", P(c_f64)),
+                ("obj_const", c_f64), ("obj_tape_len", c_i64), ("obj_tape_op", P(c_i32)), ("obj_tape_arg", P(c_f64))]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(c_i32, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, c_i64, P(c_i64), P(c_i64))
+
+# name -> (restype, argtypes); every function declared in include/katana_hip.h
+PROTOTYPES = {
+    "ktn_abi_version": (c_i32, []),
+    "ktn_default_params": (None, [P(KtnParams)]),
+    "ktn_create": (c_i32, [P(KtnParams), P(C.c_void_p)]),
+    "ktn_destroy": (None, [C.c_void_p]),
+    "ktn_last_error": (C.c_char_p, [C.c_void_p]),
+    "ktn_loadproblem": (c_i32, [C.c_void_p, c_i64, c_i64, P(c_f64), P(c_f64), P(c_f64), P(c_f64), c_i32,
+                                P(KtnNlpDesc)]),
+    "ktn_optimize": (c_i32, [C.c_void_p]),
+    "ktn_optimize_begin": (c_i32, [C.c_void_p]),
+    "ktn_ecp_step": (c_i32, [C.c_void_p, P(c_i32)]),
+    "ktn_optimize_end": (c_i32, [C.c_void_p]),
+    "ktn_reset": (c_i32, [C.c_void_p]),
+    "ktn_get_status": (c_i32, [C.c_void_p]),
+    "ktn_get_objval": (c_f64, [C.c_void_p]),
+    "ktn_get_num_var": (c_i64, [C.c_void_p]),
+    "ktn_get_solution": (c_i32, [C.c_void_p, P(c_f64), c_i64]),
+    "ktn_get_solvetime": (c_f64, [C.c_void_p]),
+    "ktn_numiters": (c_i64, [C.c_void_p]),
+    "ktn_numcuts": (c_i64, [C.c_void_p]),
+    "ktn_setwarmstart": (c_i32, [C.c_void_p, P(c_f64), c_i64]),
+    "ktn_sep_precompute": (c_i32, [C.c_void_p, P(c_f64), c_i64]),
+    "ktn_sep_num_constr": (c_i64, [C.c_void_p]),
+    "ktn_sep_jac_nnz": (c_i64, [C.c_void_p]),
+    "ktn_sep_get_g": (c_i32, [C.c_void_p, P(c_f64), c_i64]),
+    "ktn_sep_get_jac": (c_i32, [C.c_void_p, P(c_f64), c_i64]),
+    "ktn_sep_get_structure": (c_i32, [C.c_void_p, P(c_i64), P(c_i32)]),
+    "ktn_sep_isconstrsat": (c_i32, [C.c_void_p, c_i64, c_f64, c_f64, c_f64]),
+    "ktn_sep_gencut": (c_i32, [C.c_void_p, c_i64, P(c_i32), P(c_f64), P(c_i64), P(c_f64)]),
+    "ktn_sep_sweep": (c_i32, [C.c_void_p, c_f64, P(c_i64), P(c_f64)]),
+    "ktn_lp_num_rows": (c_i64, [C.c_void_p]),
+    "ktn_lp_nnz": (c_i64, [C.c_void_p]),
+    "ktn_lp_get_rows": (c_i32, [C.c_void_p, P(c_i64), P(c_i32), P(c_f64), P(c_f64), P(c_f64)]),
+    "ktn_lp_get_objective": (c_i32, [C.c_void_p, P(c_f64), c_i64, P(c_f64)]),
+    "ktn_lp_get_duals": (c_i32, [C.c_void_p, P(c_f64), c_i64]),
+    "ktn_lp_solve": (c_i32, [C.c_void_p, c_f64, c_f64, P(c_i32), P(c_i64)]),
+    "ktn_lp_pdhg_raw": (c_i32, [C.c_void_p, P(c_f64), P(c_f64), c_f64, c_f64, c_i64, P(c_f64), P(c_f64)]),
+    "ktn_num_lp_sols": (c_i64, [C.c_void_p]),
+    "ktn_get_lp_sol": (c_i32, [C.c_void_p, c_i64, P(c_f64), c_i64]),
+    "ktn_get_stat": (c_f64, [C.c_void_p, C.c_char_p]),
+    "ktn_set_shard": (c_i32, [C.c_void_p, c_i32, c_i32]),
+    "ktn_set_exchange": (c_i32, [C.c_void_p, EXCHANGE_FN, C.c_void_p]),
+}
+
+_lib = None
+
+
+class KatanaHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libkatana_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load the HIP library (once).  Fails loudly when it has not been built: there is no
+    CPU path to fall back to."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libkatana_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950).  The Katana HIP engine has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)      # AttributeError here == ABI symbol missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(handle, code):
+    if code < 0:
+        msg = lib().ktn_last_error(handle)
+        raise KatanaHipError(code, msg.decode() if msg else "")
+    return code

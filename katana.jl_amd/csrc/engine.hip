@@ -1,0 +1,1255 @@
+// engine.hip -- host side of the Katana ECP engine + the C ABI of include/katana_hip.h.
+//
+// Mirrors, function by function, the reference's driver (src/model.jl) with every piece of
+// arithmetic on the device:
+//   Engine::loadproblem   <- loadproblem!   src/model.jl:81-173
+//   Engine::boundroutine  <- boundroutine   src/model.jl:175-197
+//   Engine::begin/step/end<- optimize!      src/model.jl:219-319
+//   Engine::sweep         <- precompute! + isconstrsat + gencut + round_coefs + _addcut
+//   Engine::lp_solve      <- solve(m.linear_model)  (GLPK in the reference) replaced by a
+//                            restarted, reflected Halpern PDHG on the growing cut matrix
+// The CPU mirror of the LP algorithm used by the tests is oracle/pdlp_mirror.py
+// (solve_lp_halpern); it is test infrastructure and never linked or called from here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <limits>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+#include "prims.hpp"
+
+namespace ktn {
+
+static const double kInf = std::numeric_limits<double>::infinity();
+
+__global__ __launch_bounds__(kBlock) void k_finite_sq_partial(int64_t n, const double* __restrict__ a,
+                                                              double* __restrict__ partials) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double v = a[i];
+        if (isfinite(v)) acc += v * v;
+    }
+    __shared__ double sh[kBlock / 64];
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = 0.0;
+        for (int k = 0; k < kBlock / 64; ++k) v += sh[k];
+        partials[blockIdx.x] = v;
+    }
+}
+
+static inline int pick_group(double avg_len) {
+    int g = 4;
+    while (g < 64 && g < avg_len) g <<= 1;
+    return g;
+}
+
+#define LAUNCH_G(G, KERNEL, count, stream, ...)                                                          \
+    do {                                                                                                 \
+        const int64_t cnt__ = (count);                                                                   \
+        if (cnt__ > 0) {                                                                                 \
+            switch (G) {                                                                                 \
+                case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(ceil_div(cnt__ * 4, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break;   \
+                case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(ceil_div(cnt__ * 8, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break;   \
+                case 16: hipLaunchKernelGGL((KERNEL<16>), dim3(ceil_div(cnt__ * 16, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+                case 32: hipLaunchKernelGGL((KERNEL<32>), dim3(ceil_div(cnt__ * 32, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+                default: hipLaunchKernelGGL((KERNEL<64>), dim3(ceil_div(cnt__ * 64, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+
+#define LAUNCH_GB(G, KERNEL, B, count, stream, ...)                                                      \
+    do {                                                                                                 \
+        const int64_t cnt__ = (count);                                                                   \
+        if (cnt__ > 0) {                                                                                 \
+            switch (G) {                                                                                 \
+                case 4: hipLaunchKernelGGL((KERNEL<4, B>), dim3(ceil_div(cnt__ * 4, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break;   \
+                case 8: hipLaunchKernelGGL((KERNEL<8, B>), dim3(ceil_div(cnt__ * 8, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break;   \
+                case 16: hipLaunchKernelGGL((KERNEL<16, B>), dim3(ceil_div(cnt__ * 16, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+                case 32: hipLaunchKernelGGL((KERNEL<32, B>), dim3(ceil_div(cnt__ * 32, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+                default: hipLaunchKernelGGL((KERNEL<64, B>), dim3(ceil_div(cnt__ * 64, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+
+#define LAUNCH_1(KERNEL, count, stream, ...)                                                             \
+    do {                                                                                                 \
+        const int64_t cnt__ = (count);                                                                   \
+        if (cnt__ > 0) hipLaunchKernelGGL(KERNEL, dim3(ceil_div(cnt__, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); \
+    } while (0)
+
+struct LpResult {
+    int status = KTN_STATUS_NONE;   // OPTIMAL / USERLIMIT
+    int64_t iters = 0;
+    double pobj = 0.0, dobj = 0.0, row_viol = 0.0, gap = 0.0;
+};
+
+struct Engine {
+    ktn_params prm;
+    std::string err;
+    hipStream_t stream = nullptr;
+    int device = 0;
+
+    // ---- problem (host) ----
+    bool loaded = false;
+    int64_t n0 = 0, m0 = 0;        // original sizes
+    int64_t n_lp = 0;              // LP variables (n0, or n0+1 with the epigraph variable)
+    int64_t m_ext = 0;             // rows of the extended structure = m0 + 1 (objective row last)
+    int64_t nnz_ext = 0;
+    int sense = KTN_MIN;
+    bool obj_linear = true;
+    bool has_inf_bound = false;
+    std::vector<int64_t> h_rowptr;
+    std::vector<int32_t> h_col;
+    std::vector<uint8_t> h_rowkind;
+    std::vector<double> h_lb, h_ub;      // per extended row
+    std::vector<int32_t> h_nlrows;
+    int64_t m_nl = 0, n_tape_nl = 0;
+    int grp_sweep = 32;
+
+    // ---- device NLP ----
+    DBuf<int64_t> d_rowptr, d_nodeptr;
+    DBuf<int32_t> d_col, d_nodeop, d_nodea, d_nodeb;
+    DBuf<uint8_t> d_akind, d_rowkind, d_padzero;
+    DBuf<double> d_p0, d_p1, d_rconst, d_lb, d_ub, d_nodec, d_nodeval, d_nodeadj;
+    DBuf<int32_t> d_nlrows, d_allrows, d_taperows_all, d_taperows_nl;
+    // sweep state
+    DBuf<double> d_g, d_jac, d_bconst, d_maxc, d_xs, d_ray, d_scal;
+    DBuf<int32_t> d_nonfin, d_violslots, d_anynf;
+    DBuf<int64_t> d_flag, d_cnt, d_rank, d_cntscan, d_lastcut;
+    DBuf<char> d_scantmp;
+    bool have_precompute = false;
+
+    // ---- LP ----
+    DBuf<int64_t> lp_rowptr;
+    DBuf<int32_t> lp_col;
+    DBuf<double> lp_val, lp_lo, lp_hi, lp_y, lp_c, lp_l, lp_u, lp_x;
+    double c0 = 0.0;
+    int64_t M = 0, NNZ = 0, M_base = 0, NNZ_base = 0;
+    int64_t numcuts = 0, numcuts_base = 0;
+    bool lp_dirty = true;
+    // CSC mirror + scaling + PDHG workspace
+    DBuf<int64_t> c_ptr, c_cnt;
+    DBuf<int32_t> c_row;
+    DBuf<double> c_val, c_sval, r_sval;
+    DBuf<uint64_t> k_in, k_out;
+    DBuf<uint32_t> p_in, p_out;
+    DBuf<char> d_sorttmp;
+    DBuf<double> dr, dc, statr, statc, ch, lh, uh, loh, hih, xh, yh, x0h, y0h, xth, yth, xbar, pv, pw, box;
+    DBuf<double> partials, chkout;
+    double omega = 1.0;
+    bool have_omega = false;
+    int grp_rows = 8, grp_cols = 8;
+
+    // ---- run state ----
+    int status = KTN_STATUS_NONE;
+    int lp_status = KTN_STATUS_OPTIMAL;
+    int64_t iter = 0;
+    double soltime = 0.0, objval = std::numeric_limits<double>::quiet_NaN();
+    double last_maxviol = 1e300;
+    double obj_prev = kInf;
+    bool allsat = false, begun = false, tight_done = false;
+    std::chrono::steady_clock::time_point t_start;
+    std::vector<std::vector<double>> lp_sols;
+    std::map<std::string, double> stats;
+    // profiling events
+    std::vector<hipEvent_t> ev_pool;
+    struct EvRec { int kind; size_t a, b; double bytes; };
+    std::vector<EvRec> ev_recs;
+    size_t ev_used = 0;
+
+    explicit Engine(const ktn_params& p) : prm(p) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            throw Error(KTN_E_NODEVICE, "no HIP device visible: the Katana HIP engine has no CPU path");
+        if (prm.device >= 0) {
+            KTN_HIP(hipSetDevice(prm.device));
+            device = prm.device;
+        } else {
+            KTN_HIP(hipGetDevice(&device));
+        }
+        KTN_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        partials.resize((size_t)kRedBlocks * kChkQ * 2, stream);
+        chkout.resize(kChkQ * 2 + 8, stream);
+        d_scal.resize(8, stream);
+        d_anynf.resize(2, stream);
+    }
+    ~Engine() {
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    void sync() { KTN_HIP(hipStreamSynchronize(stream)); }
+    void check_launch() { KTN_HIP(hipGetLastError()); }
+
+    // ------------------------------------------------------------------ profiling ---
+    size_t ev_get() {
+        if (ev_used == ev_pool.size()) {
+            hipEvent_t e;
+            KTN_HIP(hipEventCreate(&e));
+            ev_pool.push_back(e);
+        }
+        return ev_used++;
+    }
+    void ev_flush() {   // stream must be synchronised
+        static const char* names[3] = {"kx", "ky", "sweep_eval"};
+        for (auto& r : ev_recs) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev_pool[r.a], ev_pool[r.b]) == hipSuccess) {
+                std::string k = names[r.kind];
+                stats[k + "_time_s"] += ms * 1e-3;
+                stats[k + "_launches"] += 1.0;
+                stats[k + "_bytes"] += r.bytes;
+            }
+        }
+        ev_recs.clear();
+        ev_used = 0;
+    }
+
+    // --------------------------------------------------------------- reductions ---
+    double dev_dot(int64_t n, const double* a, const double* b) {
+        hipLaunchKernelGGL(k_dot_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, a, b, partials.p);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, stream, partials.p, kRedBlocks, chkout.p + 2 * kChkQ);
+        double v = 0.0;
+        KTN_HIP(hipMemcpyAsync(&v, chkout.p + 2 * kChkQ, sizeof(double), hipMemcpyDeviceToHost, stream));
+        sync();
+        return v;
+    }
+    double dev_finite_sq(int64_t n, const double* a) {
+        hipLaunchKernelGGL(k_finite_sq_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, a, partials.p);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, stream, partials.p, kRedBlocks, chkout.p + 2 * kChkQ);
+        double v = 0.0;
+        KTN_HIP(hipMemcpyAsync(&v, chkout.p + 2 * kChkQ, sizeof(double), hipMemcpyDeviceToHost, stream));
+        sync();
+        return v;
+    }
+    void exclusive_scan(const int64_t* in, int64_t* out, size_t n) {
+        size_t need = scan_i64_temp_bytes(n);
+        d_scantmp.resize(need + 16, stream);
+        KTN_HIP(exclusive_scan_i64(d_scantmp.p, need, in, out, n, stream));
+    }
+
+    NlpDev nlp_view() {
+        NlpDev P;
+        P.rowptr = d_rowptr.p; P.col = d_col.p; P.akind = d_akind.p; P.p0 = d_p0.p; P.p1 = d_p1.p;
+        P.rconst = d_rconst.p; P.row_kind = d_rowkind.p; P.pad_zero = d_padzero.p; P.lb = d_lb.p; P.ub = d_ub.p;
+        P.node_ptr = d_nodeptr.p; P.node_op = d_nodeop.p; P.node_a = d_nodea.p; P.node_b = d_nodeb.p;
+        P.node_c = d_nodec.p; P.node_val = d_nodeval.p; P.node_adj = d_nodeadj.p;
+        return P;
+    }
+    SweepOut sweep_view() {
+        SweepOut O;
+        O.g = d_g.p; O.jac = d_jac.p; O.bconst = d_bconst.p; O.maxc = d_maxc.p; O.nonfin = d_nonfin.p;
+        O.flag = d_flag.p; O.cnt = d_cnt.p; O.maxviol = d_scal.p; O.any_nonfin = d_anynf.p;
+        return O;
+    }
+    LpRows lp_view() {
+        LpRows L;
+        L.rowptr = lp_rowptr.p; L.col = lp_col.p; L.val = lp_val.p; L.lo = lp_lo.p; L.hi = lp_hi.p; L.y = lp_y.p;
+        return L;
+    }
+
+    // ================================================================ loadproblem ===
+    void loadproblem(int64_t num_var, int64_t num_constr, const double* l_var, const double* u_var,
+                     const double* l_constr, const double* u_constr, int32_t sense_, const ktn_nlp_desc* d);
+    void evaluate_all(const double* d_x);
+    void reset();
+
+    // ================================================================ separator =====
+    // precompute! for every row of the extended structure (jac materialised)
+    void precompute_all(const double* d_x) {
+        NlpDev P = nlp_view();
+        SweepOut O = sweep_view();
+        LAUNCH_G(grp_sweep, k_sep_eval, m_ext, stream, P, d_allrows.p, m_ext, d_x, 0.0, 1, 0, O);
+        LAUNCH_1(k_tape_eval, (int64_t)d_taperows_all.n, stream, P, d_taperows_all.p, (int64_t)d_taperows_all.n, d_x, O);
+        // cut constants / maxima of tape rows from the materialised Jacobian (flags unused here)
+        KTN_HIP(hipMemsetAsync(d_scal.p, 0, sizeof(double), stream));
+        KTN_HIP(hipMemsetAsync(d_anynf.p, 0, sizeof(int32_t), stream));
+        LAUNCH_1(k_gj_stats, m_ext, stream, P, d_allrows.p, m_ext, d_x, 0.0, (int)KTN_ROW_TAPE, O);
+        check_launch();
+    }
+
+    // the batched {isconstrsat, gencut, round_coefs, _addcut} over the NL rows
+    void sweep(const double* d_x, double f_tol, int64_t* nviol_out, double* maxviol_out, bool* nonfinite_out) {
+        auto t0 = std::chrono::steady_clock::now();
+        *nviol_out = 0;
+        *maxviol_out = 0.0;
+        *nonfinite_out = false;
+        stats["sweeps"] += 1.0;
+        if (m_nl == 0) return;
+        NlpDev P = nlp_view();
+        SweepOut O = sweep_view();
+        KTN_HIP(hipMemsetAsync(d_scal.p, 0, sizeof(double), stream));
+        KTN_HIP(hipMemsetAsync(d_anynf.p, 0, sizeof(int32_t), stream));
+        size_t ea = 0, eb = 0;
+        if (prm.profile) { ea = ev_get(); KTN_HIP(hipEventRecord(ev_pool[ea], stream)); }
+        LAUNCH_G(grp_sweep, k_sep_eval, m_nl, stream, P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O);
+        if (prm.profile) {
+            eb = ev_get(); KTN_HIP(hipEventRecord(ev_pool[eb], stream));
+            ev_recs.push_back({2, ea, eb, sweep_bytes});
+        }
+        if (n_tape_nl > 0) {
+            LAUNCH_1(k_tape_eval, n_tape_nl, stream, P, d_taperows_nl.p, n_tape_nl, d_x, O);
+            LAUNCH_1(k_gj_stats, m_nl, stream, P, d_nlrows.p, m_nl, d_x, f_tol, (int)KTN_ROW_TAPE, O);
+        }
+        check_launch();
+        exclusive_scan(d_flag.p, d_rank.p, (size_t)m_nl);
+        exclusive_scan(d_cnt.p, d_cntscan.p, (size_t)m_nl);
+        int64_t tail[4];
+        double mv = 0.0;
+        int32_t anynf = 0;
+        KTN_HIP(hipMemcpyAsync(&tail[0], d_flag.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
+        KTN_HIP(hipMemcpyAsync(&tail[1], d_rank.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
+        KTN_HIP(hipMemcpyAsync(&tail[2], d_cnt.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
+        KTN_HIP(hipMemcpyAsync(&tail[3], d_cntscan.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
+        KTN_HIP(hipMemcpyAsync(&mv, d_scal.p, 8, hipMemcpyDeviceToHost, stream));
+        KTN_HIP(hipMemcpyAsync(&anynf, d_anynf.p, 4, hipMemcpyDeviceToHost, stream));
+        sync();
+        if (prm.profile) ev_flush();
+        const int64_t V = tail[0] + tail[1], nnzV = tail[2] + tail[3];
+        *nviol_out = V;
+        *maxviol_out = mv;
+        if (anynf) {   // model.jl:69-73: "Nonlinear constraint or objective likely undefined within domain"
+            *nonfinite_out = true;
+            return;
+        }
+        if (V > 0) {
+            lp_rowptr.resize((size_t)(M + V + 1), stream);
+            lp_lo.resize((size_t)(M + V), stream);
+            lp_hi.resize((size_t)(M + V), stream);
+            lp_y.resize((size_t)(M + V), stream);
+            lp_col.resize((size_t)(NNZ + nnzV), stream);
+            lp_val.resize((size_t)(NNZ + nnzV), stream);
+            d_violslots.resize((size_t)V, stream);
+            LpRows L = lp_view();
+            LAUNCH_1(k_compact, m_nl, stream, P, d_nlrows.p, m_nl, d_flag.p, d_rank.p, d_cntscan.p, d_bconst.p, M, NNZ, L,
+                     d_violslots.p, d_lastcut.p, (int)prm.lp_dual_inherit);
+            LAUNCH_G(grp_sweep, k_emit, V, stream, P, d_nlrows.p, d_violslots.p, V, d_x, d_jac.p, d_maxc.p,
+                     prm.cut_coef_rng, 1, M, L);
+            check_launch();
+            M += V;
+            NNZ += nnzV;
+            numcuts += V;
+            lp_dirty = true;
+        }
+        sync();
+        stats["sep_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    double sweep_bytes = 0.0;
+
+    // ================================================================ LP ============
+    void rebuild_csc();
+    void compute_scaling(bool identity);
+    LpResult lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling = false);
+    void pdhg_raw(const double* x0, const double* y0, double eta, double omega_, int64_t iters, double* x_out,
+                  double* y_out);
+
+    // ================================================================ ECP driver ====
+    bool recession_ray();
+    void boundroutine();
+    void begin();
+    void step(int32_t* done);
+    void end();
+};
+
+// ------------------------------------------------------------------------------------
+// loadproblem!  src/model.jl:81-173
+// ------------------------------------------------------------------------------------
+static void postfix_to_nodes(const int32_t* op, const double* arg, int64_t len, const int32_t* rcols, int64_t rlen,
+                             int64_t jac_base, std::vector<int32_t>& nop, std::vector<int32_t>& na,
+                             std::vector<int32_t>& nb, std::vector<double>& nc) {
+    std::vector<int32_t> st;
+    const int64_t base = (int64_t)nop.size();
+    for (int64_t t = 0; t < len; ++t) {
+        const int o = op[t];
+        int32_t a = 0, b = 0;
+        double c = 0.0;
+        switch (o) {
+            case KTN_OP_CONST: c = arg[t]; break;
+            case KTN_OP_VAR: {
+                const int32_t v = (int32_t)arg[t];
+                int64_t slot = -1;
+                for (int64_t s = 0; s < rlen; ++s) if (rcols[s] == v) { slot = s; break; }
+                if (slot < 0) throw Error(KTN_E_INVALID, "tape variable missing from the row's Jacobian structure");
+                a = v;
+                b = (int32_t)(jac_base + slot);
+            } break;
+            case KTN_OP_ADD: case KTN_OP_SUB: case KTN_OP_MUL: case KTN_OP_DIV:
+                if (st.size() < 2) throw Error(KTN_E_INVALID, "malformed tape (binary op underflow)");
+                b = st.back(); st.pop_back();
+                a = st.back(); st.pop_back();
+                break;
+            case KTN_OP_POWC: c = arg[t];  // fallthrough
+            case KTN_OP_NEG: case KTN_OP_EXP: case KTN_OP_LOG: case KTN_OP_SQRT: case KTN_OP_SIN: case KTN_OP_COS:
+                if (st.empty()) throw Error(KTN_E_INVALID, "malformed tape (unary op underflow)");
+                a = st.back(); st.pop_back();
+                break;
+            default: throw Error(KTN_E_UNSUPPORTED, "Unsupported tape opcode " + std::to_string(o));
+        }
+        nop.push_back(o); na.push_back(a); nb.push_back(b); nc.push_back(c);
+        st.push_back((int32_t)((int64_t)nop.size() - 1 - base));
+    }
+    if (len > 0 && st.size() != 1) throw Error(KTN_E_INVALID, "malformed tape (stack not reduced to one value)");
+}
+
+void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_var, const double* u_var,
+                         const double* l_constr, const double* u_constr, int32_t sense_, const ktn_nlp_desc* d) {
+    KTN_REQUIRE(d != nullptr, "nlp description is NULL");
+    KTN_REQUIRE(num_var >= 0 && num_constr >= 0, "negative sizes");
+    KTN_REQUIRE(d->num_var == num_var && d->num_constr == num_constr, "nlp description sizes disagree with loadproblem");
+    KTN_REQUIRE(num_var < (int64_t)0x7ffffff0, "num_var too large for 32-bit column indices");
+    loaded = false;
+    n0 = num_var; m0 = num_constr; sense = sense_;
+    obj_linear = d->obj_linear != 0;
+    m_ext = m0 + 1;
+    const int64_t nnz0 = m0 ? d->rowptr[m0] : 0;
+
+    // ---- extended structure: rows 0..m0-1 + the objective row f(x) - t over n0+1 variables
+    //      (EpigraphNLPEvaluator, src/nlpeval.jl:42-63; only structural non-zeros are stored,
+    //       the reference's dense zeros are remembered in pad_zero for round_coefs)
+    h_rowptr.assign(d->rowptr, d->rowptr + m0 + 1);
+    h_col.assign(d->col, d->col + nnz0);
+    std::vector<uint8_t> akind(nnz0), padzero(m_ext, 0);
+    std::vector<double> p0(nnz0), p1(nnz0), rconst(m_ext, 0.0);
+    h_rowkind.assign(m_ext, KTN_ROW_SEP);
+    for (int64_t e = 0; e < nnz0; ++e) {
+        akind[e] = d->atom_kind ? d->atom_kind[e] : 0;
+        p0[e] = d->p0 ? d->p0[e] : 0.0;
+        p1[e] = d->p1 ? d->p1[e] : 0.0;
+        KTN_REQUIRE(h_col[e] >= 0 && h_col[e] < n0, "column index out of range");
+    }
+    for (int64_t i = 0; i < m0; ++i) {
+        h_rowkind[i] = d->row_kind ? d->row_kind[i] : KTN_ROW_SEP;
+        rconst[i] = d->rconst ? d->rconst[i] : 0.0;
+        KTN_REQUIRE(h_rowptr[i + 1] >= h_rowptr[i], "rowptr not monotone");
+    }
+    // objective row
+    std::vector<int32_t> ocols;
+    if (d->obj_kind == KTN_ROW_SEP) {
+        for (int64_t e = 0; e < d->obj_nnz; ++e) {
+            KTN_REQUIRE(d->obj_col[e] >= 0 && d->obj_col[e] < n0, "objective column out of range");
+            h_col.push_back(d->obj_col[e]);
+            akind.push_back(d->obj_atom_kind ? d->obj_atom_kind[e] : 0);
+            p0.push_back(d->obj_p0[e]);
+            p1.push_back(d->obj_p1 ? d->obj_p1[e] : 0.0);
+        }
+        h_col.push_back((int32_t)n0);   // - t
+        akind.push_back(KTN_ATOM_LIN);
+        p0.push_back(-1.0);
+        p1.push_back(0.0);
+        rconst[m0] = d->obj_const;
+        h_rowkind[m0] = KTN_ROW_SEP;
+    } else {
+        for (int64_t t = 0; t < d->obj_tape_len; ++t)
+            if (d->obj_tape_op[t] == KTN_OP_VAR) ocols.push_back((int32_t)d->obj_tape_arg[t]);
+        std::sort(ocols.begin(), ocols.end());
+        ocols.erase(std::unique(ocols.begin(), ocols.end()), ocols.end());
+        for (auto c : ocols) {
+            KTN_REQUIRE(c >= 0 && c < n0, "objective tape variable out of range");
+            h_col.push_back(c); akind.push_back(0); p0.push_back(0.0); p1.push_back(0.0);
+        }
+        h_col.push_back((int32_t)n0); akind.push_back(0); p0.push_back(0.0); p1.push_back(0.0);
+        rconst[m0] = d->obj_const;
+        h_rowkind[m0] = KTN_ROW_TAPE;
+    }
+    h_rowptr.push_back((int64_t)h_col.size());
+    nnz_ext = (int64_t)h_col.size();
+    padzero[m0] = (h_rowptr[m0 + 1] - h_rowptr[m0]) < (n0 + 1) ? 1 : 0;
+
+    // ---- tapes -> expression DAGs
+    std::vector<int64_t> nodeptr(m_ext + 1, 0);
+    std::vector<int32_t> nop, na, nb;
+    std::vector<double> nc;
+    std::vector<int32_t> tape_all;
+    for (int64_t i = 0; i < m_ext; ++i) {
+        nodeptr[i] = (int64_t)nop.size();
+        if (h_rowkind[i] != KTN_ROW_TAPE) continue;
+        tape_all.push_back((int32_t)i);
+        const int32_t* rc = h_col.data() + h_rowptr[i];
+        const int64_t rl = h_rowptr[i + 1] - h_rowptr[i];
+        if (i < m0) {
+            KTN_REQUIRE(d->tape_ptr != nullptr, "tape row without tape arrays");
+            const int64_t tb = d->tape_ptr[i], te = d->tape_ptr[i + 1];
+            postfix_to_nodes(d->tape_op + tb, d->tape_arg + tb, te - tb, rc, rl, h_rowptr[i], nop, na, nb, nc);
+        } else {
+            std::vector<int32_t> op(d->obj_tape_op, d->obj_tape_op + d->obj_tape_len);
+            std::vector<double> arg(d->obj_tape_arg, d->obj_tape_arg + d->obj_tape_len);
+            if (op.empty()) { op.push_back(KTN_OP_CONST); arg.push_back(0.0); }
+            op.push_back(KTN_OP_VAR); arg.push_back((double)n0);
+            op.push_back(KTN_OP_SUB); arg.push_back(0.0);
+            postfix_to_nodes(op.data(), arg.data(), (int64_t)op.size(), rc, rl, h_rowptr[i], nop, na, nb, nc);
+        }
+    }
+    nodeptr[m_ext] = (int64_t)nop.size();
+
+    // ---- bounds per extended row; NL row list (model.jl:115-122,144-148)
+    h_lb.assign(m_ext, 0.0);
+    h_ub.assign(m_ext, 0.0);
+    for (int64_t i = 0; i < m0; ++i) { h_lb[i] = l_constr[i]; h_ub[i] = u_constr[i]; }
+    h_nlrows.clear();
+    std::vector<int64_t> lin_rows;
+    for (int64_t i = 0; i < m0; ++i) {
+        if (d->row_linear && d->row_linear[i]) lin_rows.push_back(i);
+        else h_nlrows.push_back((int32_t)i);
+    }
+    n_lp = n0;
+    std::vector<double> lv(l_var, l_var + n0), uv(u_var, u_var + n0);
+    if (!obj_linear) {
+        n_lp = n0 + 1;                                  // @variable(m.linear_model, y)  model.jl:137-138
+        lv.push_back(-kInf);
+        uv.push_back(kInf);
+        h_lb[m0] = (sense == KTN_MAX) ? 0.0 : -kInf;    // model.jl:144
+        h_ub[m0] = (sense == KTN_MAX) ? kInf : 0.0;
+        h_nlrows.push_back((int32_t)m0);
+    }
+    m_nl = (int64_t)h_nlrows.size();
+    has_inf_bound = false;
+    for (int64_t j = 0; j < n_lp; ++j)
+        if (!std::isfinite(lv[j]) || !std::isfinite(uv[j])) has_inf_bound = true;
+
+    // ---- upload the NLP
+    d_rowptr.upload(h_rowptr, stream); d_col.upload(h_col, stream); d_akind.upload(akind, stream);
+    d_p0.upload(p0, stream); d_p1.upload(p1, stream); d_rconst.upload(rconst, stream);
+    d_rowkind.upload(h_rowkind, stream); d_padzero.upload(padzero, stream);
+    d_lb.upload(h_lb, stream); d_ub.upload(h_ub, stream);
+    d_nodeptr.upload(nodeptr, stream); d_nodeop.upload(nop, stream); d_nodea.upload(na, stream);
+    d_nodeb.upload(nb, stream); d_nodec.upload(nc, stream);
+    d_nodeval.resize(nop.size() + 1, stream); d_nodeadj.resize(nop.size() + 1, stream);
+    std::vector<int32_t> allrows(m_ext);
+    for (int64_t i = 0; i < m_ext; ++i) allrows[i] = (int32_t)i;
+    d_allrows.upload(allrows, stream);
+    d_taperows_all.upload(tape_all, stream);
+    std::vector<int32_t> tape_nl;
+    int64_t nnz_nl = 0;
+    for (auto r : h_nlrows) {
+        if (h_rowkind[r] == KTN_ROW_TAPE) tape_nl.push_back(r);
+        nnz_nl += h_rowptr[r + 1] - h_rowptr[r];
+    }
+    n_tape_nl = (int64_t)tape_nl.size();
+    d_taperows_nl.upload(tape_nl, stream);
+    d_nlrows.upload(h_nlrows, stream);
+    grp_sweep = pick_group(m_nl ? (double)nnz_nl / (double)m_nl : 4.0);
+    if (grp_sweep < 8) grp_sweep = 8;
+    // algorithmic bytes of one evaluation pass over the NL rows (DESIGN.md "sweep bytes")
+    sweep_bytes = (double)nnz_nl * (4 + 1 + 16) + 8.0 * (m_nl + 1) + 8.0 * n_lp + 8.0 * 4 * m_nl + 16.0 * m_nl;
+    const size_t mm = (size_t)std::max<int64_t>(m_ext, 1);
+    d_g.resize(mm, stream); d_bconst.resize(mm, stream); d_maxc.resize(mm, stream); d_nonfin.resize(mm, stream);
+    d_jac.resize((size_t)nnz_ext + 1, stream);
+    d_flag.resize(mm, stream); d_cnt.resize(mm, stream); d_rank.resize(mm, stream); d_cntscan.resize(mm, stream);
+    d_lastcut.resize(mm, stream);
+    d_xs.resize((size_t)n0 + 1, stream); d_ray.resize((size_t)n0 + 1, stream);
+    d_flag.zero(stream); d_cnt.zero(stream);
+
+    // ---- tangent at the origin: linear rows and (linear) objective  model.jl:110-133
+    d_xs.zero(stream);
+    precompute_all(d_xs.p);
+    std::vector<double> g0 = d_g.to_host(stream), j0 = d_jac.to_host(stream);
+    std::vector<int64_t> rp(1, 0);
+    std::vector<int32_t> rc;
+    std::vector<double> rv, rlo, rhi;
+    numcuts = 0;
+    for (auto i : lin_rows) {
+        double b = g0[i];
+        for (int64_t e = h_rowptr[i]; e < h_rowptr[i + 1]; ++e) {
+            rc.push_back(h_col[e]);
+            rv.push_back(j0[e]);
+            b += -0.0 * j0[e];
+        }
+        rp.push_back((int64_t)rc.size());
+        rlo.push_back(l_constr[i] - b);
+        rhi.push_back(u_constr[i] - b);
+        numcuts += 1;                                   // model.jl:77
+    }
+    std::vector<double> cvec(n_lp, 0.0);
+    c0 = 0.0;
+    if (obj_linear) {
+        // gencut(fsep, pt, (0,0), num_constr+1), drop the fictitious aux variable  model.jl:129-133
+        for (int64_t e = h_rowptr[m0]; e < h_rowptr[m0 + 1]; ++e)
+            if (h_col[e] < n0) cvec[h_col[e]] += j0[e];
+        c0 = g0[m0];
+    } else {
+        cvec[n0] = 1.0;                                 // @objective(m.linear_model, sense, y)  model.jl:139
+        // initial epigraph cut at the bound-box vertex  model.jl:93-97,156-164
+        bool ok = true;
+        std::vector<double> vtx(n0 + 1, 0.0);
+        for (int64_t j = 0; j < n0; ++j) {
+            const double lo = lv[j], hi = uv[j];
+            if (lo > hi) ok = false;
+            const bool lf = std::isfinite(lo), uf = std::isfinite(hi);
+            if (lf && uf) vtx[j] = (std::fabs(lo) <= std::fabs(hi)) ? lo : hi;   // GLPK non-basic rule
+            else if (lf) vtx[j] = lo;
+            else if (uf) vtx[j] = hi;
+            else vtx[j] = 0.0;
+        }
+        if (ok) {
+            KTN_HIP(hipMemcpyAsync(d_xs.p, vtx.data(), (n0 + 1) * sizeof(double), hipMemcpyHostToDevice, stream));
+            precompute_all(d_xs.p);
+            std::vector<double> g1 = d_g.to_host(stream);
+            vtx[n0] = g1[m0];                           // push!(vertex, eval_f(d, vertex))
+            KTN_HIP(hipMemcpyAsync(d_xs.p, vtx.data(), (n0 + 1) * sizeof(double), hipMemcpyHostToDevice, stream));
+            precompute_all(d_xs.p);
+            g1 = d_g.to_host(stream);
+            std::vector<double> j1 = d_jac.to_host(stream);
+            double b = g1[m0];
+            std::vector<double> coef;
+            double mx = -kInf;
+            bool finite = true;
+            for (int64_t e = h_rowptr[m0]; e < h_rowptr[m0 + 1]; ++e) {
+                coef.push_back(j1[e]);
+                b += -vtx[h_col[e]] * j1[e];
+                if (!(j1[e] <= mx)) mx = (j1[e] != j1[e]) ? j1[e] : std::max(mx, j1[e]);
+                if (!std::isfinite(j1[e])) finite = false;
+            }
+            if (padzero[m0] && !(mx != mx)) mx = std::max(mx, 0.0);
+            for (auto& cf : coef) if (cf + prm.cut_coef_rng < mx) cf = 0.0;   // round_coefs
+            if (!finite) {
+                status = KTN_STATUS_ERROR;              // _addcut: warn + :Error, no row added
+            } else {
+                for (int64_t e = h_rowptr[m0]; e < h_rowptr[m0 + 1]; ++e) {
+                    rc.push_back(h_col[e]);
+                    rv.push_back(coef[e - h_rowptr[m0]]);
+                }
+                rp.push_back((int64_t)rc.size());
+                rlo.push_back(h_lb[m0] - b);
+                rhi.push_back(h_ub[m0] - b);
+                numcuts += 1;
+            }
+        }
+    }
+    // ---- LP upload
+    M = (int64_t)rlo.size();
+    NNZ = (int64_t)rc.size();
+    lp_rowptr.upload(rp, stream); lp_col.upload(rc, stream); lp_val.upload(rv, stream);
+    lp_lo.upload(rlo, stream); lp_hi.upload(rhi, stream);
+    lp_y.resize((size_t)M, stream); lp_y.zero(stream);
+    lp_c.upload(cvec, stream); lp_l.upload(lv, stream); lp_u.upload(uv, stream);
+    lp_x.resize((size_t)n_lp, stream); lp_x.zero(stream);
+    M_base = M; NNZ_base = NNZ; numcuts_base = numcuts;
+    sync();
+    loaded = true;
+    const int keep_status = status;
+    reset();
+    if (keep_status == KTN_STATUS_ERROR) status = KTN_STATUS_ERROR;
+}
+
+void Engine::reset() {
+    M = M_base; NNZ = NNZ_base; numcuts = numcuts_base;
+    lp_rowptr.n = (size_t)M + 1; lp_col.n = (size_t)NNZ; lp_val.n = (size_t)NNZ;
+    lp_lo.n = lp_hi.n = lp_y.n = (size_t)M;
+    lp_y.zero(stream); lp_x.zero(stream);
+    std::vector<int64_t> neg1((size_t)std::max<int64_t>(m_ext, 1), -1);
+    d_lastcut.upload(neg1, stream);
+    lp_dirty = true; have_omega = false; have_precompute = false;
+    status = KTN_STATUS_NONE; lp_status = KTN_STATUS_OPTIMAL;
+    iter = 0; soltime = 0.0; objval = std::numeric_limits<double>::quiet_NaN();
+    last_maxviol = 1e300; obj_prev = kInf; allsat = false; begun = false; tight_done = false;
+    lp_sols.clear();
+    sync();
+}
+
+// ------------------------------------------------------------------------------------
+// LP: column mirror, scaling, PDHG
+// ------------------------------------------------------------------------------------
+void Engine::rebuild_csc() {
+    c_ptr.resize((size_t)n_lp + 1, stream);
+    c_cnt.resize((size_t)n_lp + 1, stream);
+    c_cnt.zero(stream);
+    c_row.resize((size_t)NNZ + 1, stream);
+    c_val.resize((size_t)NNZ + 1, stream);
+    if (NNZ > 0) {
+        k_in.resize((size_t)NNZ, stream); k_out.resize((size_t)NNZ, stream);
+        p_in.resize((size_t)NNZ, stream); p_out.resize((size_t)NNZ, stream);
+        LAUNCH_1(k_csc_keys, M, stream, M, lp_rowptr.p, lp_col.p, k_in.p, p_in.p, c_cnt.p);
+        check_launch();
+    }
+    exclusive_scan(c_cnt.p, c_ptr.p, (size_t)n_lp + 1);
+    if (NNZ > 0) {
+        int bits = 1;
+        while (((int64_t)1 << bits) < n_lp + 1 && bits < 31) ++bits;
+        size_t need = sort_pairs_temp_bytes((size_t)NNZ);
+        d_sorttmp.resize(need + 16, stream);
+        KTN_HIP(sort_pairs_u64_u32(d_sorttmp.p, need, k_in.p, k_out.p, p_in.p, p_out.p, (size_t)NNZ, 32 + bits, stream));
+        LAUNCH_1(k_csc_gather, NNZ, stream, NNZ, k_out.p, p_out.p, lp_val.p, c_row.p, c_val.p);
+        check_launch();
+    }
+    lp_dirty = false;
+}
+
+void Engine::compute_scaling(bool identity) {
+    dr.resize((size_t)std::max<int64_t>(M, 1), stream);
+    dc.resize((size_t)n_lp, stream);
+    statr.resize((size_t)std::max<int64_t>(M, 1), stream);
+    statc.resize((size_t)n_lp, stream);
+    LAUNCH_1(k_fill, M, stream, M, dr.p, 1.0);
+    LAUNCH_1(k_fill, n_lp, stream, n_lp, dc.p, 1.0);
+    if (!identity && M > 0) {
+        for (int it = 0; it <= prm.lp_ruiz_iters; ++it) {
+            const int mode = (it == prm.lp_ruiz_iters) ? 1 : 0;   // last pass: Pock-Chambolle (alpha = 1)
+            LAUNCH_1(k_scale_stat, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, mode, statr.p);
+            LAUNCH_1(k_scale_stat, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, statc.p);
+            LAUNCH_1(k_scale_apply, M, stream, M, dr.p, statr.p);
+            LAUNCH_1(k_scale_apply, n_lp, stream, n_lp, dc.p, statc.p);
+        }
+    }
+    r_sval.resize((size_t)NNZ + 1, stream);
+    c_sval.resize((size_t)NNZ + 1, stream);
+    LAUNCH_1(k_scale_vals, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, r_sval.p);
+    LAUNCH_1(k_scale_vals, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, c_sval.p);
+    check_launch();
+}
+
+LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling) {
+    auto t0 = std::chrono::steady_clock::now();
+    LpResult R;
+    if (lp_dirty) rebuild_csc();
+    compute_scaling(identity_scaling);
+    const int64_t n = n_lp, m = M;
+    const size_t mm = (size_t)std::max<int64_t>(m, 1);
+    ch.resize(n, stream); lh.resize(n, stream); uh.resize(n, stream); xh.resize(n, stream);
+    x0h.resize(n, stream); xth.resize(n, stream); xbar.resize(n, stream); pv.resize(n, stream);
+    loh.resize(mm, stream); hih.resize(mm, stream); yh.resize(mm, stream); y0h.resize(mm, stream);
+    yth.resize(mm, stream); pw.resize(mm, stream);
+    const double sgn = (sense == KTN_MAX) ? -1.0 : 1.0;
+    LAUNCH_1(k_prep_cols, n, stream, n, lp_c.p, lp_l.p, lp_u.p, dc.p, lp_x.p, (mode == 1 ? box.p : (double*)nullptr), sgn,
+             mode, ch.p, lh.p, uh.p, xh.p);
+    LAUNCH_1(k_prep_rows, m, stream, m, lp_lo.p, lp_hi.p, dr.p, lp_y.p, mode, loh.p, hih.p, yh.p);
+    check_launch();
+    const double avg_r = m ? (double)NNZ / (double)m : 1.0, avg_c = n ? (double)NNZ / (double)n : 1.0;
+    grp_rows = pick_group(avg_r);
+    grp_cols = pick_group(avg_c);
+    SpMat A{lp_rowptr.p, lp_col.p, r_sval.p};
+    SpMat AT{c_ptr.p, c_row.p, c_sval.p};
+
+    // step size: power iteration on A^'A^
+    double smax = 0.0;
+    if (m > 0 && NNZ > 0) {
+        LAUNCH_1(k_fill, n, stream, n, pv.p, 1.0 / std::sqrt((double)n));
+        double vnorm = 1.0;
+        for (int it = 0; it < 20; ++it) {
+            LAUNCH_G(grp_rows, k_spmv, m, stream, m, A, pv.p, pw.p);
+            LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, pw.p, xbar.p);
+            const double nv = std::sqrt(dev_dot(n, xbar.p, xbar.p));
+            if (!(nv > 0.0)) break;
+            smax = std::sqrt(nv / std::max(vnorm, 1e-300));
+            LAUNCH_1(k_axpy_scaled, n, stream, n, xbar.p, 1.0 / nv, pv.p);
+            vnorm = 1.0;
+        }
+    }
+    const double eta = 0.998 / std::max(smax, 1e-12);
+    const double nc2 = dev_dot(n, ch.p, ch.p);
+    const double nb2 = (m > 0) ? dev_finite_sq(m, loh.p) + dev_finite_sq(m, hih.p) : 0.0;
+    const double omega_ref = (nc2 > 0.0 && nb2 > 0.0) ? std::sqrt(nc2 / nb2) : 1.0;
+    double om = (have_omega && mode == 0) ? omega : omega_ref;
+    const double rho = 1.0;
+    const double cinf_scale = 1.0;
+
+    KTN_HIP(hipMemcpyAsync(x0h.p, xh.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    if (m > 0) KTN_HIP(hipMemcpyAsync(y0h.p, yh.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+
+    const double ky_bytes = (double)NNZ * 12 + 8.0 * (m + 1) + 8.0 * 5 * m + 8.0 * n;
+    const double kx_bytes = (double)NNZ * 12 + 8.0 * (n + 1) + 8.0 * 7 * n + 8.0 * m;
+    int64_t k = 0, it = 0;
+    double r0 = 0.0, r_prev = 0.0;
+    R.status = KTN_STATUS_USERLIMIT;
+    const int64_t max_it = prm.lp_max_iter;
+    const int chk = std::max(1, prm.lp_check_every);
+    while (it < max_it) {
+        const double tau = eta / om, sigma = eta * om;
+        const bool check = (it % chk == 0) || k == 0;
+        if (!check) {
+            const double w = (double)(k + 1) / (double)(k + 2);
+            size_t e0 = 0, e1 = 0, e2 = 0;
+            if (prm.profile) { e0 = ev_get(); KTN_HIP(hipEventRecord(ev_pool[e0], stream)); }
+            LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+            if (prm.profile) { e1 = ev_get(); KTN_HIP(hipEventRecord(ev_pool[e1], stream)); }
+            LAUNCH_GB(grp_rows, k_pdhg_y, true, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, rho);
+            if (prm.profile) {
+                e2 = ev_get(); KTN_HIP(hipEventRecord(ev_pool[e2], stream));
+                ev_recs.push_back({0, e0, e1, kx_bytes});
+                ev_recs.push_back({1, e1, e2, ky_bytes});
+            }
+            ++k; ++it;
+            continue;
+        }
+        // ---- check iteration: PDHG step without update, KKT + fixed-point residual
+        LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, 0.0, rho);
+        LAUNCH_GB(grp_rows, k_pdhg_y, false, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, 0.0, rho);
+        hipLaunchKernelGGL(k_chk_rows, dim3(kRedBlocks), dim3(kBlock), 0, stream, m, A, xh.p, xth.p, yh.p, yth.p, y0h.p,
+                           loh.p, hih.p, dr.p, partials.p);
+        hipLaunchKernelGGL(k_chk_final, dim3(1), dim3(64), 0, stream, partials.p, kRedBlocks, chkout.p);
+        hipLaunchKernelGGL(k_chk_cols, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, AT, xh.p, xth.p, x0h.p, yth.p, ch.p,
+                           lh.p, uh.p, dc.p, partials.p + (size_t)kRedBlocks * kChkQ);
+        hipLaunchKernelGGL(k_chk_final, dim3(1), dim3(64), 0, stream, partials.p + (size_t)kRedBlocks * kChkQ, kRedBlocks,
+                           chkout.p + kChkQ);
+        check_launch();
+        double q[2 * kChkQ];
+        KTN_HIP(hipMemcpyAsync(q, chkout.p, sizeof(q), hipMemcpyDeviceToHost, stream));
+        sync();
+        if (prm.profile) ev_flush();
+        const double dyAdx = q[0], dy2 = q[1], dobj_rows = q[2], dy0sq = q[3], yt2 = q[4], pviol = q[12];
+        const double dx2 = q[kChkQ + 5], pobj = q[kChkQ + 6], dobj_cols = q[kChkQ + 7], dx0sq = q[kChkQ + 8],
+                     xt2 = q[kChkQ + 9], dres = q[kChkQ + 13];
+        const double dobj = dobj_rows + dobj_cols;
+        const double r2 = om / eta * dx2 - 2.0 * dyAdx + dy2 / (eta * om);
+        const double r = std::sqrt(std::max(r2, 0.0));
+        const double gap = std::fabs(pobj - dobj) / (1.0 + std::fabs(pobj) + std::fabs(dobj));
+        if (k == 0) { r0 = r; r_prev = r; }
+        R.pobj = pobj; R.dobj = dobj; R.row_viol = pviol; R.gap = gap;
+        const bool done = (pviol <= tol_p) && (gap <= tol_g) && (dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2)));
+        if (done || !(r == r)) {
+            R.status = done ? KTN_STATUS_OPTIMAL : KTN_STATUS_ERROR;
+            ++it;
+            break;
+        }
+        const bool restart = k > 0 && (r <= 0.2 * r0 || (r <= 0.8 * r0 && r > r_prev) || (double)k >= 0.36 * (double)(it + 1));
+        r_prev = r;
+        if (restart) {
+            const double dx = std::sqrt(dx0sq), dy = std::sqrt(dy0sq);
+            // guarded primal-weight update (oracle/pdlp_mirror.py solve_lp_halpern)
+            if (dx > 1e-8 * (1.0 + std::sqrt(xt2)) && dy > 1e-8 * (1.0 + std::sqrt(yt2))) {
+                om = std::exp(0.5 * std::log(dy / dx) + 0.5 * std::log(om));
+                om = std::min(std::max(om, omega_ref * 1e-3), omega_ref * 1e3);
+            }
+            KTN_HIP(hipMemcpyAsync(xh.p, xth.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            KTN_HIP(hipMemcpyAsync(x0h.p, xth.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            if (m > 0) {
+                KTN_HIP(hipMemcpyAsync(yh.p, yth.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                KTN_HIP(hipMemcpyAsync(y0h.p, yth.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            }
+            stats["lp_restarts"] += 1.0;
+            k = 0;
+            ++it;
+            continue;
+        }
+        const double w = (double)(k + 1) / (double)(k + 2);
+        LAUNCH_1(k_halpern, n, stream, n, xh.p, xth.p, x0h.p, w, rho);
+        LAUNCH_1(k_halpern, m, stream, m, yh.p, yth.p, y0h.p, w, rho);
+        ++k; ++it;
+    }
+    R.iters = it;
+    // un-scale the last PDHG point (xt, yt)
+    if (mode == 0) {
+        LAUNCH_1(k_unscale, n, stream, n, xth.p, dc.p, lp_x.p);
+        LAUNCH_1(k_unscale, m, stream, m, yth.p, dr.p, lp_y.p);
+        omega = om;
+        have_omega = true;
+        objval = sgn * R.pobj + c0;
+    } else {
+        LAUNCH_1(k_unscale, n, stream, n, xth.p, dc.p, d_ray.p);
+    }
+    check_launch();
+    sync();
+    if (prm.profile) ev_flush();
+    stats["pdhg_iters"] += (double)it;
+    stats["lp_solves"] += 1.0;
+    stats["lp_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return R;
+}
+
+void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double omega_, int64_t iters, double* x_out,
+                      double* y_out) {
+    if (lp_dirty) rebuild_csc();
+    compute_scaling(true);
+    const int64_t n = n_lp, m = M;
+    const size_t mm = (size_t)std::max<int64_t>(m, 1);
+    ch.resize(n, stream); lh.resize(n, stream); uh.resize(n, stream); xh.resize(n, stream);
+    x0h.resize(n, stream); xth.resize(n, stream); xbar.resize(n, stream);
+    loh.resize(mm, stream); hih.resize(mm, stream); yh.resize(mm, stream); y0h.resize(mm, stream); yth.resize(mm, stream);
+    const double sgn = (sense == KTN_MAX) ? -1.0 : 1.0;
+    KTN_HIP(hipMemcpyAsync(lp_x.p, x0, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (m > 0) KTN_HIP(hipMemcpyAsync(lp_y.p, y0, m * sizeof(double), hipMemcpyHostToDevice, stream));
+    LAUNCH_1(k_prep_cols, n, stream, n, lp_c.p, lp_l.p, lp_u.p, dc.p, lp_x.p, (double*)nullptr, sgn, 0, ch.p, lh.p, uh.p, xh.p);
+    LAUNCH_1(k_prep_rows, m, stream, m, lp_lo.p, lp_hi.p, dr.p, lp_y.p, 0, loh.p, hih.p, yh.p);
+    grp_rows = pick_group(m ? (double)NNZ / (double)m : 1.0);
+    grp_cols = pick_group(n ? (double)NNZ / (double)n : 1.0);
+    SpMat A{lp_rowptr.p, lp_col.p, r_sval.p};
+    SpMat AT{c_ptr.p, c_row.p, c_sval.p};
+    KTN_HIP(hipMemcpyAsync(x0h.p, xh.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    if (m > 0) KTN_HIP(hipMemcpyAsync(y0h.p, yh.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    const double tau = eta / omega_, sigma = eta * omega_;
+    for (int64_t k = 0; k < iters; ++k) {
+        const double w = (double)(k + 1) / (double)(k + 2);
+        LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, 1.0);
+        LAUNCH_GB(grp_rows, k_pdhg_y, true, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, 1.0);
+    }
+    check_launch();
+    KTN_HIP(hipMemcpyAsync(x_out, xh.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (m > 0) KTN_HIP(hipMemcpyAsync(y_out, yh.p, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+}
+
+// ------------------------------------------------------------------------------------
+// ECP driver
+// ------------------------------------------------------------------------------------
+// "status == :Unbounded" + getunboundedray: solve the recession-cone LP (oracle/lp.py).
+bool Engine::recession_ray() {
+    box.resize((size_t)n_lp, stream);
+    LAUNCH_1(k_fill, n_lp, stream, n_lp, box.p, 1.0);
+    if (!obj_linear) {
+        KTN_HIP(hipMemsetAsync(d_scal.p + 1, 0, sizeof(double), stream));
+        LAUNCH_1(k_aux_box, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, (int32_t)n0, d_scal.p + 1);
+        double w = 0.0;
+        KTN_HIP(hipMemcpyAsync(&w, d_scal.p + 1, 8, hipMemcpyDeviceToHost, stream));
+        sync();
+        LAUNCH_1(k_fill, 1, stream, (int64_t)1, box.p + n0, 1.0 + w);
+    }
+    LpResult R = lp_solve(1e-9, 1e-7, 1);
+    return R.status == KTN_STATUS_OPTIMAL && R.pobj < -1e-6;
+}
+
+// boundroutine  src/model.jl:175-197 with the ray in d_ray
+void Engine::boundroutine() {
+    for (int nn = 2; nn <= 1023; ++nn) {
+        const double s = std::ldexp(1.0, nn);
+        LAUNCH_1(k_axpy_scaled, n_lp, stream, n_lp, d_ray.p, s, d_xs.p);
+        int64_t nviol = 0;
+        double mv = 0.0;
+        bool nonfin = false;
+        sweep(d_xs.p, prm.f_tol, &nviol, &mv, &nonfin);
+        if (nonfin) { status = KTN_STATUS_ERROR; return; }
+        if (nviol > 0) break;   // !allsat -> stop searching in this direction
+    }
+}
+
+void Engine::begin() {
+    KTN_REQUIRE(loaded, "optimize! before loadproblem!");
+    t_start = std::chrono::steady_clock::now();
+    begun = true;
+    lp_status = KTN_STATUS_OPTIMAL;
+    if (status == KTN_STATUS_ERROR) return;
+    if (has_inf_bound) {       // presolve: resolve an initially-unbounded LP  model.jl:228-247
+        int64_t i = 0;
+        bool unb = recession_ray();
+        while (unb && i < n_lp) {
+            boundroutine();
+            if (status == KTN_STATUS_ERROR) return;
+            unb = recession_ray();
+            ++i;
+        }
+        if (unb) { lp_status = KTN_STATUS_UNBOUNDED; status = KTN_STATUS_UNBOUNDED; }
+    }
+}
+
+void Engine::step(int32_t* done) {
+    KTN_REQUIRE(begun, "ktn_ecp_step before ktn_optimize_begin");
+    *done = 1;
+    if (status == KTN_STATUS_ERROR || status == KTN_STATUS_UNBOUNDED) return;
+    if (allsat || iter >= prm.iter_cap) return;          // while !allsat && m.iter < iter_cap  model.jl:257
+    iter += 1;
+    const double floor_p = prm.lp_tol_floor * prm.f_tol;
+    double tol_p = std::min(std::max(prm.lp_tol_scale * last_maxviol, floor_p), prm.lp_tol_cap);
+    double tol_g = std::min(std::max(tol_p, prm.lp_gap_floor), prm.lp_gap_cap);
+    LpResult R = lp_solve(tol_p, tol_g, 0);
+    lp_status = R.status;
+    if (R.status != KTN_STATUS_OPTIMAL) { status = R.status; return; }   // model.jl:261-263
+    if (prm.vis_data) lp_sols.push_back(lp_x.to_host(stream));          // model.jl:267
+    int64_t nviol = 0;
+    double mv = 0.0;
+    bool nonfin = false;
+    sweep(lp_x.p, prm.f_tol, &nviol, &mv, &nonfin);                      // model.jl:268-283
+    if (nonfin) { status = KTN_STATUS_ERROR; return; }
+    last_maxviol = mv;
+    const bool sat_now = (nviol == 0);
+    // inexact-LP rule (DESIGN.md "LP tolerance schedule"): all rows satisfied only counts once
+    // the LP itself was solved to the floor tolerance
+    if (sat_now && tol_p > floor_p * (1.0 + 1e-12)) last_maxviol = 0.0;
+    else allsat = sat_now;
+    const double obj = objval;                                           // model.jl:287-289
+    const double obj_delta = std::fabs((obj_prev - obj) / obj);
+    obj_prev = obj;
+    if (prm.log_level > 0 && (iter % prm.log_level == 0 || allsat))
+        std::printf("%-10lld %-15lld %-15lld %-20.3e %-15lld\n", (long long)iter, (long long)numcuts, (long long)nviol, mv,
+                    (long long)R.iters);
+    if (obj_delta <= prm.obj_eps) { allsat = true; }                     // model.jl:306-308 (break)
+    *done = (allsat || iter >= prm.iter_cap) ? 1 : 0;
+}
+
+void Engine::end() {
+    soltime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();   // model.jl:311
+    if (status == KTN_STATUS_ERROR || status == KTN_STATUS_UNBOUNDED) return;
+    if (lp_status != KTN_STATUS_OPTIMAL) { status = lp_status; return; }
+    status = (iter >= prm.iter_cap) ? KTN_STATUS_USERLIMIT : KTN_STATUS_OPTIMAL;                   // model.jl:313-317
+}
+
+}  // namespace ktn
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+using ktn::Engine;
+
+struct ktn_handle_s {
+    Engine* eng = nullptr;
+    std::string err;
+};
+
+#define KTN_TRY(h, ...)                                                      \
+    if (!(h) || !(h)->eng) return KTN_E_INVALID;                             \
+    try {                                                                    \
+        __VA_ARGS__                                                          \
+    } catch (const ktn::Error& e) {                                          \
+        (h)->err = e.what();                                                 \
+        return e.code;                                                       \
+    } catch (const std::bad_alloc&) {                                        \
+        (h)->err = "host out of memory";                                     \
+        return KTN_E_NOMEM;                                                  \
+    } catch (const std::exception& e) {                                      \
+        (h)->err = e.what();                                                 \
+        return KTN_E_INVALID;                                                \
+    }
+
+extern "C" {
+
+int ktn_abi_version(void) { return KTN_ABI_VERSION; }
+
+void ktn_default_params(ktn_params* p) {
+    if (!p) return;
+    p->f_tol = 1e-6; p->cut_coef_rng = 1e9; p->log_level = 10; p->iter_cap = 10000; p->obj_eps = -1.0;
+    p->vis_data = 0; p->device = -1;
+    p->lp_max_iter = 2000000; p->lp_check_every = 64; p->lp_ruiz_iters = 10;
+    p->lp_tol_scale = 0.1; p->lp_tol_floor = 0.3; p->lp_tol_cap = 1e-3; p->lp_gap_floor = 1e-7; p->lp_gap_cap = 1e-4;
+    p->lp_dual_inherit = 1; p->profile = 0;
+}
+
+int ktn_create(const ktn_params* p, ktn_handle* out) {
+    if (!out) return KTN_E_INVALID;
+    *out = nullptr;
+    ktn_params prm;
+    if (p) prm = *p; else ktn_default_params(&prm);
+    ktn_handle h = new (std::nothrow) ktn_handle_s();
+    if (!h) return KTN_E_NOMEM;
+    try {
+        h->eng = new Engine(prm);
+    } catch (const ktn::Error& e) {
+        std::fprintf(stderr, "ktn_create: %s\n", e.what());
+        int code = e.code;
+        delete h;
+        return code;
+    } catch (...) {
+        delete h;
+        return KTN_E_INVALID;
+    }
+    *out = h;
+    return KTN_OK;
+}
+
+void ktn_destroy(ktn_handle h) {
+    if (!h) return;
+    delete h->eng;
+    delete h;
+}
+
+const char* ktn_last_error(ktn_handle h) { return h ? h->err.c_str() : "invalid handle"; }
+
+int ktn_loadproblem(ktn_handle h, int64_t num_var, int64_t num_constr, const double* l_var, const double* u_var,
+                    const double* l_constr, const double* u_constr, int32_t sense, const ktn_nlp_desc* d) {
+    KTN_TRY(h, { h->eng->loadproblem(num_var, num_constr, l_var, u_var, l_constr, u_constr, sense, d); return KTN_OK; })
+}
+
+int ktn_optimize_begin(ktn_handle h) { KTN_TRY(h, { h->eng->begin(); return KTN_OK; }) }
+int ktn_ecp_step(ktn_handle h, int32_t* done) {
+    KTN_TRY(h, { int32_t d = 1; h->eng->step(&d); if (done) *done = d; return KTN_OK; })
+}
+int ktn_optimize_end(ktn_handle h) { KTN_TRY(h, { h->eng->end(); return h->eng->status; }) }
+
+int ktn_optimize(ktn_handle h) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        e->begin();
+        int32_t done = (e->status == KTN_STATUS_ERROR || e->status == KTN_STATUS_UNBOUNDED) ? 1 : 0;
+        while (!done) e->step(&done);
+        e->end();
+        return e->status;
+    })
+}
+
+int ktn_reset(ktn_handle h) { KTN_TRY(h, { KTN_REQUIRE(h->eng->loaded, "reset before loadproblem"); h->eng->reset(); return KTN_OK; }) }
+
+int ktn_get_status(ktn_handle h) { return (h && h->eng) ? h->eng->status : KTN_E_INVALID; }
+double ktn_get_objval(ktn_handle h) { return (h && h->eng) ? h->eng->objval : NAN; }
+int64_t ktn_get_num_var(ktn_handle h) { return (h && h->eng) ? h->eng->n_lp : -1; }
+int ktn_get_solution(ktn_handle h, double* x_out, int64_t n) {
+    KTN_TRY(h, {
+        KTN_REQUIRE(h->eng->loaded && x_out && n >= h->eng->n_lp, "solution buffer too small");
+        h->eng->lp_x.download(x_out, (size_t)h->eng->n_lp, h->eng->stream);
+        return KTN_OK;
+    })
+}
+double ktn_get_solvetime(ktn_handle h) { return (h && h->eng) ? h->eng->soltime : NAN; }
+int64_t ktn_numiters(ktn_handle h) { return (h && h->eng) ? h->eng->iter : -1; }
+int64_t ktn_numcuts(ktn_handle h) { return (h && h->eng) ? h->eng->numcuts : -1; }
+int ktn_setwarmstart(ktn_handle h, const double* x, int64_t n) {   // src/model.jl:335: ignored
+    (void)x; (void)n;
+    return (h && h->eng) ? KTN_OK : KTN_E_INVALID;
+}
+
+// ---- separator API
+int ktn_sep_precompute(ktn_handle h, const double* xstar, int64_t n) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && xstar && n >= e->n_lp, "precompute!: xstar too short");
+        e->d_xs.zero(e->stream);
+        KTN_HIP(hipMemcpyAsync(e->d_xs.p, xstar, (size_t)std::min<int64_t>(n, e->n0 + 1) * sizeof(double),
+                               hipMemcpyHostToDevice, e->stream));
+        e->precompute_all(e->d_xs.p);
+        e->sync();
+        e->have_precompute = true;
+        return KTN_OK;
+    })
+}
+int64_t ktn_sep_num_constr(ktn_handle h) { return (h && h->eng) ? (h->eng->obj_linear ? h->eng->m0 : h->eng->m_ext) : -1; }
+int64_t ktn_sep_jac_nnz(ktn_handle h) {
+    if (!h || !h->eng || !h->eng->loaded) return -1;
+    Engine* e = h->eng;
+    return e->obj_linear ? e->h_rowptr[e->m0] : e->nnz_ext;
+}
+int ktn_sep_get_g(ktn_handle h, double* g_out, int64_t m) {
+    KTN_TRY(h, {
+        KTN_REQUIRE(h->eng->have_precompute && g_out && m <= h->eng->m_ext, "get_g before precompute! or bad size");
+        h->eng->d_g.download(g_out, (size_t)m, h->eng->stream);
+        return KTN_OK;
+    })
+}
+int ktn_sep_get_jac(ktn_handle h, double* jac_out, int64_t nnz) {
+    KTN_TRY(h, {
+        KTN_REQUIRE(h->eng->have_precompute && jac_out && nnz <= h->eng->nnz_ext, "get_jac before precompute! or bad size");
+        h->eng->d_jac.download(jac_out, (size_t)nnz, h->eng->stream);
+        return KTN_OK;
+    })
+}
+int ktn_sep_get_structure(ktn_handle h, int64_t* rowptr_out, int32_t* col_out) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded, "structure before loadproblem!");
+        const int64_t m = e->obj_linear ? e->m0 : e->m_ext;
+        std::memcpy(rowptr_out, e->h_rowptr.data(), (size_t)(m + 1) * sizeof(int64_t));
+        std::memcpy(col_out, e->h_col.data(), (size_t)e->h_rowptr[m] * sizeof(int32_t));
+        return KTN_OK;
+    })
+}
+int ktn_sep_isconstrsat(ktn_handle h, int64_t i, double lb, double ub, double f_tol) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->have_precompute && i >= 0 && i < e->m_ext, "isconstrsat: bad row or no precompute!");
+        double g = 0.0;
+        KTN_HIP(hipMemcpyAsync(&g, e->d_g.p + i, 8, hipMemcpyDeviceToHost, e->stream));
+        e->sync();
+        return ((g >= lb - f_tol) && (g <= ub + f_tol)) ? 1 : 0;
+    })
+}
+int ktn_sep_gencut(ktn_handle h, int64_t i, int32_t* cols, double* coefs, int64_t* nnz, double* constant) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->have_precompute && i >= 0 && i < e->m_ext && nnz, "gencut: bad row or no precompute!");
+        const int64_t beg = e->h_rowptr[i], len = e->h_rowptr[i + 1] - beg;
+        KTN_REQUIRE(*nnz >= len, "gencut: output capacity too small");
+        std::memcpy(cols, e->h_col.data() + beg, (size_t)len * sizeof(int32_t));
+        if (len) KTN_HIP(hipMemcpyAsync(coefs, e->d_jac.p + beg, (size_t)len * 8, hipMemcpyDeviceToHost, e->stream));
+        KTN_HIP(hipMemcpyAsync(constant, e->d_bconst.p + i, 8, hipMemcpyDeviceToHost, e->stream));
+        e->sync();
+        *nnz = len;
+        return KTN_OK;
+    })
+}
+int ktn_sep_sweep(ktn_handle h, double f_tol, int64_t* nviol, double* maxviol) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->have_precompute, "sweep before precompute!");
+        int64_t nv = 0; double mv = 0.0; bool nf = false;
+        e->sweep(e->d_xs.p, f_tol, &nv, &mv, &nf);
+        if (nviol) *nviol = nv;
+        if (maxviol) *maxviol = mv;
+        if (nf) e->status = KTN_STATUS_ERROR;
+        return KTN_OK;
+    })
+}
+
+// ---- LP introspection
+int64_t ktn_lp_num_rows(ktn_handle h) { return (h && h->eng) ? h->eng->M : -1; }
+int64_t ktn_lp_nnz(ktn_handle h) { return (h && h->eng) ? h->eng->NNZ : -1; }
+int ktn_lp_get_rows(ktn_handle h, int64_t* rowptr, int32_t* col, double* val, double* lo, double* hi) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded, "no problem loaded");
+        e->lp_rowptr.download(rowptr, (size_t)e->M + 1, e->stream);
+        e->lp_col.download(col, (size_t)e->NNZ, e->stream);
+        e->lp_val.download(val, (size_t)e->NNZ, e->stream);
+        e->lp_lo.download(lo, (size_t)e->M, e->stream);
+        e->lp_hi.download(hi, (size_t)e->M, e->stream);
+        return KTN_OK;
+    })
+}
+int ktn_lp_get_objective(ktn_handle h, double* c_out, int64_t n, double* c0) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && n >= e->n_lp, "objective buffer too small");
+        e->lp_c.download(c_out, (size_t)e->n_lp, e->stream);
+        if (c0) *c0 = e->c0;
+        return KTN_OK;
+    })
+}
+int ktn_lp_get_duals(ktn_handle h, double* y_out, int64_t m) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && m >= e->M, "dual buffer too small");
+        e->lp_y.download(y_out, (size_t)e->M, e->stream);
+        return KTN_OK;
+    })
+}
+int ktn_lp_solve(ktn_handle h, double row_tol, double gap_tol, int32_t* lp_status, int64_t* pdhg_iters) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded, "no problem loaded");
+        ktn::LpResult R = e->lp_solve(row_tol, gap_tol, 0);
+        if (lp_status) *lp_status = R.status;
+        if (pdhg_iters) *pdhg_iters = R.iters;
+        return KTN_OK;
+    })
+}
+int ktn_lp_pdhg_raw(ktn_handle h, const double* x0, const double* y0, double eta, double omega, int64_t iters,
+                    double* x_out, double* y_out) {
+    KTN_TRY(h, {
+        KTN_REQUIRE(h->eng->loaded, "no problem loaded");
+        h->eng->pdhg_raw(x0, y0, eta, omega, iters, x_out, y_out);
+        return KTN_OK;
+    })
+}
+int64_t ktn_num_lp_sols(ktn_handle h) { return (h && h->eng) ? (int64_t)h->eng->lp_sols.size() : -1; }
+int ktn_get_lp_sol(ktn_handle h, int64_t k, double* x_out, int64_t n) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(k >= 0 && k < (int64_t)e->lp_sols.size() && n >= (int64_t)e->lp_sols[k].size(), "bad lp_sols index");
+        std::memcpy(x_out, e->lp_sols[k].data(), e->lp_sols[k].size() * sizeof(double));
+        return KTN_OK;
+    })
+}
+
+double ktn_get_stat(ktn_handle h, const char* name) {
+    if (!h || !h->eng || !name) return NAN;
+    auto it = h->eng->stats.find(name);
+    return it == h->eng->stats.end() ? 0.0 : it->second;
+}
+
+int ktn_set_shard(ktn_handle h, int32_t rank, int32_t world) {
+    (void)rank;
+    if (!h || !h->eng) return KTN_E_INVALID;
+    if (world == 1) return KTN_OK;
+    h->err = "in-library sharding is not implemented in this round: shard in the host (katana.jl_amd/distributed.py)";
+    return KTN_E_UNSUPPORTED;
+}
+int ktn_set_exchange(ktn_handle h, ktn_exchange_fn fn, void* user) {
+    (void)fn; (void)user;
+    if (!h || !h->eng) return KTN_E_INVALID;
+    h->err = "in-library exchange is not implemented in this round: exchange in the host (katana.jl_amd/distributed.py)";
+    return KTN_E_UNSUPPORTED;
+}
+
+}  // extern "C"

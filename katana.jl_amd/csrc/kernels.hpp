@@ -1,0 +1,643 @@
+// kernels.hpp -- CDNA4 (gfx950) device kernels of the Katana ECP engine.
+//
+// All arithmetic is FP64 (SURVEY.md section 7 hard part 5) and HBM/L2-bandwidth bound:
+// sparse gather-multiply-reduce, no dense contraction, hence no MFMA.  Work is mapped
+// as "G lanes per sparse row" with G in {4..64} a power of two chosen from the average
+// row length, so that a 64-wide wavefront serves 64/G rows, consecutive lanes read
+// consecutive CSR entries (coalesced) and the row reduction is a __shfl_xor butterfly
+// inside the wavefront (no LDS, no barriers).
+//
+//   separator sweep   k_sep_eval / k_tape_eval / k_gj_stats / k_compact / k_emit
+//                     == precompute! + isconstrsat + gencut(linear_oa_cut) + round_coefs
+//                        + _addcut   (src/separators.jl:111-120, src/algorithms.jl:3-18,
+//                                     src/model.jl:68-79,200-207,272-283)
+//   LP (replaces GLPK) k_pdhg_x / k_pdhg_y / k_chk_* / scaling kernels
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/katana_hip.h"
+
+namespace ktn {
+
+constexpr int kBlock = 256;
+constexpr int kRedBlocks = 256;   // blocks of the two-stage deterministic reductions
+constexpr int kChkQ = 16;         // quantities per check partial
+
+// ---------------------------------------------------------------- small helpers ----
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ double group_max(double v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ int group_or(int v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
+    return v;
+}
+// max with NaN poisoning (Julia's maximum() propagates NaN; fmax would drop it)
+__device__ __forceinline__ double nanmax(double a, double b) {
+    return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b);
+}
+template <int G>
+__device__ __forceinline__ double group_nanmax(double v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v = nanmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// order-independent (hence deterministic) atomic max for non-negative doubles
+__device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {
+    if (v != v) v = __builtin_inf();
+    if (v > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+// ------------------------------------------------------------- separable atoms ----
+__device__ __forceinline__ void atom_eval(int kind, double a, double b, double x, double& val, double& der) {
+    switch (kind) {
+        case KTN_ATOM_LIN: val = a * x; der = a; break;
+        case KTN_ATOM_QUAD: { double d = x - b; val = a * d * d; der = 2.0 * a * d; } break;
+        case KTN_ATOM_EXP: { double e = a * exp(b * x); val = e; der = b * e; } break;
+        default: { double s = x + b; val = -a * log(s); der = -a / s; } break;   // KTN_ATOM_NEGLOG
+    }
+}
+
+// Device view of the (epigraph-lifted) NLP: CSR Jacobian structure + row programs.
+struct NlpDev {
+    const int64_t* rowptr;
+    const int32_t* col;
+    const uint8_t* akind;
+    const double* p0;
+    const double* p1;
+    const double* rconst;
+    const uint8_t* row_kind;
+    const uint8_t* pad_zero;   // row has implicit zero coefficients (dense epigraph row, src/nlpeval.jl:49-54)
+    const double* lb;
+    const double* ub;
+    // expression DAG of the tape rows (nodes in evaluation order)
+    const int64_t* node_ptr;
+    const int32_t* node_op;
+    const int32_t* node_a;
+    const int32_t* node_b;
+    const double* node_c;
+    double* node_val;
+    double* node_adj;
+};
+
+// Per-NL-row outputs of the evaluation stage
+struct SweepOut {
+    double* g;         // [m]   constraint values  (separators.jl:113)
+    double* jac;       // [nnz] Jacobian values    (separators.jl:112); separable rows write it only if materialize
+    double* bconst;    // [m]   cut constant b = g - sum x*_c J_c   (algorithms.jl:8,15)
+    double* maxc;      // [m]   signed max coefficient (model.jl:201)
+    int32_t* nonfin;   // [m]   any non-finite coefficient (model.jl:69)
+    int64_t* flag;     // [m_nl] 1 if violated (by NL slot)
+    int64_t* cnt;      // [m_nl] row nnz if violated else 0
+    double* maxviol;   // [1]
+    int32_t* any_nonfin;  // [1] some violated row has a non-finite coefficient
+};
+
+// precompute! + isconstrsat for separable rows: G lanes per row.
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_sep_eval(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
+                                                     const double* __restrict__ x, double f_tol, int materialize,
+                                                     int only_flagged_nl, SweepOut O) {
+    const int64_t gid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (gid >= m_nl) return;
+    const int32_t r = nl_rows[gid];
+    if (P.row_kind[r] != KTN_ROW_SEP) return;
+    const int64_t beg = P.rowptr[r], end = P.rowptr[r + 1];
+    double acc_g = 0.0, acc_dot = 0.0, mx = -__builtin_inf();
+    int nf = 0;
+    for (int64_t e = beg + lane; e < end; e += G) {
+        const int c = P.col[e];
+        double val, der;
+        const double xv = x[c];
+        atom_eval(P.akind[e], P.p0[e], P.p1[e], xv, val, der);
+        acc_g += val;
+        acc_dot += xv * der;
+        mx = nanmax(mx, der);
+        nf |= !isfinite(der);
+        if (materialize) O.jac[e] = der;
+    }
+    acc_g = group_sum<G>(acc_g);
+    acc_dot = group_sum<G>(acc_dot);
+    mx = group_nanmax<G>(mx);
+    nf = group_or<G>(nf);
+    if (lane == 0) {
+        const double g = acc_g + P.rconst[r];
+        if (P.pad_zero[r]) mx = nanmax(mx, 0.0);
+        O.g[r] = g;
+        O.bconst[r] = g - acc_dot;
+        O.maxc[r] = mx;
+        O.nonfin[r] = nf;
+        if (only_flagged_nl) {
+            const double lb = P.lb[r], ub = P.ub[r];
+            const bool sat = (g >= lb - f_tol) && (g <= ub + f_tol);   // separators.jl:120 (NaN -> violated)
+            O.flag[gid] = sat ? 0 : 1;
+            O.cnt[gid] = sat ? 0 : (end - beg);
+            if (!sat) {
+                atomic_max_nonneg(O.maxviol, fmax(g - ub, lb - g));
+                if (nf) atomicOr(O.any_nonfin, 1);
+            }
+        }
+    }
+}
+
+// precompute! for tape rows: one thread per row, forward sweep then reverse sweep over
+// the row's expression DAG.  Derivative conventions follow the oracle (oracle/sexpr.py):
+// log' = 1/v, sqrt' = 0.5/sqrt(v), pow: 2 -> 2v, 1 -> 1, else p v^(p-1).
+__global__ __launch_bounds__(kBlock) void k_tape_eval(NlpDev P, const int32_t* __restrict__ tape_rows, int64_t n_tape,
+                                                      const double* __restrict__ x, SweepOut O) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n_tape) return;
+    const int32_t r = tape_rows[t];
+    const int64_t nb = P.node_ptr[r], ne = P.node_ptr[r + 1];
+    for (int64_t e = P.rowptr[r]; e < P.rowptr[r + 1]; ++e) O.jac[e] = 0.0;
+    if (ne == nb) { O.g[r] = P.rconst[r]; return; }
+    double* val = P.node_val;
+    double* adj = P.node_adj;
+    for (int64_t i = nb; i < ne; ++i) {
+        const int op = P.node_op[i];
+        const double a = (op >= KTN_OP_ADD) ? val[nb + P.node_a[i]] : 0.0;
+        const double b = (op >= KTN_OP_ADD && op <= KTN_OP_DIV) ? val[nb + P.node_b[i]] : 0.0;
+        double v;
+        switch (op) {
+            case KTN_OP_CONST: v = P.node_c[i]; break;
+            case KTN_OP_VAR: v = x[P.node_a[i]]; break;
+            case KTN_OP_ADD: v = a + b; break;
+            case KTN_OP_SUB: v = a - b; break;
+            case KTN_OP_MUL: v = a * b; break;
+            case KTN_OP_DIV: v = a / b; break;
+            case KTN_OP_NEG: v = -a; break;
+            case KTN_OP_POWC: v = pow(a, P.node_c[i]); break;
+            case KTN_OP_EXP: v = exp(a); break;
+            case KTN_OP_LOG: v = log(a); break;
+            case KTN_OP_SQRT: v = sqrt(a); break;
+            case KTN_OP_SIN: v = sin(a); break;
+            default: v = cos(a); break;
+        }
+        val[i] = v;
+        adj[i] = 0.0;
+    }
+    adj[ne - 1] = 1.0;
+    for (int64_t i = ne - 1; i >= nb; --i) {
+        const int op = P.node_op[i];
+        const double w = adj[i];
+        if (op == KTN_OP_CONST) continue;
+        if (op == KTN_OP_VAR) { O.jac[P.node_b[i]] += w; continue; }
+        const int64_t ia = nb + P.node_a[i];
+        const double a = val[ia];
+        switch (op) {
+            case KTN_OP_ADD: adj[ia] += w; adj[nb + P.node_b[i]] += w; break;
+            case KTN_OP_SUB: adj[ia] += w; adj[nb + P.node_b[i]] -= w; break;
+            case KTN_OP_MUL: { const int64_t ib = nb + P.node_b[i]; const double b = val[ib];
+                               adj[ia] += w * b; adj[ib] += w * a; } break;
+            case KTN_OP_DIV: { const int64_t ib = nb + P.node_b[i]; const double b = val[ib];
+                               adj[ia] += w * (1.0 / b); adj[ib] += w * (-(val[i] / b)); } break;
+            case KTN_OP_NEG: adj[ia] -= w; break;
+            case KTN_OP_POWC: { const double p = P.node_c[i];
+                                const double d = (p == 2.0) ? 2.0 * a : (p == 1.0 ? 1.0 : p * pow(a, p - 1.0));
+                                adj[ia] += w * d; } break;
+            case KTN_OP_EXP: adj[ia] += w * val[i]; break;
+            case KTN_OP_LOG: adj[ia] += w * (1.0 / a); break;
+            case KTN_OP_SQRT: adj[ia] += w * (0.5 / val[i]); break;
+            case KTN_OP_SIN: adj[ia] += w * cos(a); break;
+            default: adj[ia] += w * (-sin(a)); break;
+        }
+    }
+    O.g[r] = val[ne - 1] + P.rconst[r];
+}
+
+// linear_oa_cut constant / round_coefs max / finite check / isconstrsat from a
+// materialised Jacobian row (tape rows; also the host-evaluator fallback of section 8b).
+// One thread per row, entries in storage order == the reference's left-to-right order.
+__global__ __launch_bounds__(kBlock) void k_gj_stats(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
+                                                     const double* __restrict__ x, double f_tol, int kind_filter,
+                                                     SweepOut O) {
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= m_nl) return;
+    const int32_t r = nl_rows[gid];
+    if (kind_filter >= 0 && P.row_kind[r] != kind_filter) return;
+    const int64_t beg = P.rowptr[r], end = P.rowptr[r + 1];
+    const double g = O.g[r];
+    double b = g, mx = -__builtin_inf();
+    int nf = 0;
+    for (int64_t e = beg; e < end; ++e) {
+        const double der = O.jac[e];
+        b += -x[P.col[e]] * der;
+        mx = nanmax(mx, der);
+        nf |= !isfinite(der);
+    }
+    if (P.pad_zero[r]) mx = nanmax(mx, 0.0);
+    O.bconst[r] = b;
+    O.maxc[r] = mx;
+    O.nonfin[r] = nf;
+    const double lb = P.lb[r], ub = P.ub[r];
+    const bool sat = (g >= lb - f_tol) && (g <= ub + f_tol);
+    O.flag[gid] = sat ? 0 : 1;
+    O.cnt[gid] = sat ? 0 : (end - beg);
+    if (!sat) {
+        atomic_max_nonneg(O.maxviol, fmax(g - ub, lb - g));
+        if (nf) atomicOr(O.any_nonfin, 1);
+    }
+}
+
+// Growing row-sparse LP  lo <= A x <= hi  (CSR, rows only ever appended).
+struct LpRows {
+    int64_t* rowptr;
+    int32_t* col;
+    double* val;
+    double* lo;
+    double* hi;
+    double* y;   // duals (unscaled), warm start across ECP iterations
+};
+
+// _addcut bookkeeping after the scans: row bounds (lb - b, ub - b), new rowptr entries,
+// violated-row list, and the dual warm start (new cut inherits the dual of the previous
+// cut of the same NL row).
+__global__ __launch_bounds__(kBlock) void k_compact(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
+                                                    const int64_t* __restrict__ flag, const int64_t* __restrict__ rank,
+                                                    const int64_t* __restrict__ cnt_scan, const double* __restrict__ bconst,
+                                                    int64_t base_row, int64_t base_nnz, LpRows L,
+                                                    int32_t* __restrict__ viol_slots, int64_t* __restrict__ last_cut,
+                                                    int inherit) {
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= m_nl) return;
+    if (!flag[gid]) return;
+    const int32_t r = nl_rows[gid];
+    const int64_t v = rank[gid];
+    const int64_t R = base_row + v;
+    const int64_t len = P.rowptr[r + 1] - P.rowptr[r];
+    L.rowptr[R + 1] = base_nnz + cnt_scan[gid] + len;   // rowptr[base_row] already == base_nnz
+    const double b = bconst[r];
+    L.lo[R] = P.lb[r] - b;   // model.jl:74-75; a NaN constant gives NaN bounds -> vacuous side in the LP
+    L.hi[R] = P.ub[r] - b;
+    viol_slots[v] = (int32_t)gid;
+    double y0 = 0.0;
+    const int64_t prev = last_cut[gid];
+    if (inherit && prev >= 0) { y0 = L.y[prev]; L.y[prev] = 0.0; }
+    L.y[R] = y0;
+    last_cut[gid] = R;
+}
+
+// gencut + round_coefs + row append: G lanes per violated row.
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_emit(NlpDev P, const int32_t* __restrict__ nl_rows,
+                                                 const int32_t* __restrict__ viol_slots, int64_t n_viol,
+                                                 const double* __restrict__ x, const double* __restrict__ jac,
+                                                 const double* __restrict__ maxc, double cut_coef_rng, int round_coefs,
+                                                 int64_t base_row, LpRows L) {
+    const int64_t v = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (v >= n_viol) return;
+    const int32_t r = nl_rows[viol_slots[v]];
+    const int64_t beg = P.rowptr[r], end = P.rowptr[r + 1];
+    const int64_t dst = L.rowptr[base_row + v];
+    const bool sep = P.row_kind[r] == KTN_ROW_SEP;
+    const double mx = maxc[r];
+    for (int64_t e = beg + lane; e < end; e += G) {
+        const int c = P.col[e];
+        double der;
+        if (sep) { double val; atom_eval(P.akind[e], P.p0[e], P.p1[e], x[c], val, der); }
+        else der = jac[e];
+        if (round_coefs && (der + cut_coef_rng < mx)) der = 0.0;   // model.jl:202-206 (signed max)
+        L.col[dst + (e - beg)] = c;
+        L.val[dst + (e - beg)] = der;
+    }
+}
+
+// ================================================================ LP: PDHG ========
+// Scaled problem  A^ = Dr A Dc.  CSR (rows) serves A x, the CSC mirror serves A'y.
+struct SpMat {
+    const int64_t* ptr;
+    const int32_t* idx;
+    const double* val;   // scaled values
+};
+
+// x-step + reflected Halpern update.  One group per column (CSC gather of y).
+//   xt = clip(x - tau (c - A'y), l, u);  xbar = 2 xt - x
+//   UPDATE: x <- w ((1+rho) xt - rho x) + (1-w) x0     else: store xt
+template <int G, bool UPDATE>
+__global__ __launch_bounds__(kBlock) void k_pdhg_x(int64_t n, SpMat AT, const double* __restrict__ y,
+                                                   double* __restrict__ x, const double* __restrict__ x0,
+                                                   double* __restrict__ xt, double* __restrict__ xbar,
+                                                   const double* __restrict__ c, const double* __restrict__ l,
+                                                   const double* __restrict__ u, double tau, double w, double rho) {
+    const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (j >= n) return;
+    const int64_t beg = AT.ptr[j], end = AT.ptr[j + 1];
+    double acc = 0.0;
+    for (int64_t e = beg + lane; e < end; e += G) acc += AT.val[e] * y[AT.idx[e]];
+    acc = group_sum<G>(acc);
+    if (lane == 0) {
+        const double xv = x[j];
+        const double xtv = clampd(xv - tau * (c[j] - acc), l[j], u[j]);
+        xbar[j] = 2.0 * xtv - xv;
+        if (UPDATE) x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0[j];
+        else xt[j] = xtv;
+    }
+}
+
+// y-step + reflected Halpern update.  One group per row (CSR gather of xbar).
+//   v = y - sigma A xbar;  yt = v + sigma clip(-v/sigma, lo, hi)
+template <int G, bool UPDATE>
+__global__ __launch_bounds__(kBlock) void k_pdhg_y(int64_t m, SpMat A, const double* __restrict__ xbar,
+                                                   double* __restrict__ y, const double* __restrict__ y0,
+                                                   double* __restrict__ yt, const double* __restrict__ lo,
+                                                   const double* __restrict__ hi, double sigma, double w, double rho) {
+    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (i >= m) return;
+    const int64_t beg = A.ptr[i], end = A.ptr[i + 1];
+    double acc = 0.0;
+    for (int64_t e = beg + lane; e < end; e += G) acc += A.val[e] * xbar[A.idx[e]];
+    acc = group_sum<G>(acc);
+    if (lane == 0) {
+        const double yv = y[i];
+        const double v = yv - sigma * acc;
+        const double ytv = v + sigma * clampd(-v / sigma, lo[i], hi[i]);
+        if (UPDATE) y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0[i];
+        else yt[i] = ytv;
+    }
+}
+
+// Halpern update after a check iteration that neither terminated nor restarted.
+__global__ __launch_bounds__(kBlock) void k_halpern(int64_t n, double* __restrict__ z, const double* __restrict__ zt,
+                                                    const double* __restrict__ z0, double w, double rho) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) z[i] = w * ((1.0 + rho) * zt[i] - rho * z[i]) + (1.0 - w) * z0[i];
+}
+
+// Block-level accumulation of kChkQ quantities: [0..11] sums, [12..15] maxima.
+struct ChkAcc {
+    double s[kChkQ];
+    __device__ void init() {
+#pragma unroll
+        for (int q = 0; q < kChkQ; ++q) s[q] = 0.0;
+    }
+};
+__device__ __forceinline__ void chk_block_store(ChkAcc& a, double* partials) {
+    __shared__ double sh[kChkQ][kBlock / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < kChkQ; ++q) {
+        double v = a.s[q];
+        if (q < 12) v = group_sum<64>(v); else v = group_max<64>(v);
+        if (lane == 0) sh[q][wv] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kChkQ) {
+        const int q = threadIdx.x;
+        double v = sh[q][0];
+        for (int k = 1; k < kBlock / 64; ++k) v = (q < 12) ? v + sh[q][k] : fmax(v, sh[q][k]);
+        partials[(int64_t)blockIdx.x * kChkQ + q] = v;
+    }
+}
+__global__ void k_chk_final(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+    const int q = threadIdx.x;
+    if (q >= kChkQ) return;
+    double v = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        const double p = partials[(int64_t)b * kChkQ + q];
+        v = (q < 12) ? v + p : fmax(v, p);
+    }
+    out[q] = v;
+}
+
+// KKT / fixed-point quantities, row side (grid-stride, one thread per row: check
+// iterations run once per `lp_check_every` PDHG iterations and are not the hot kernel).
+//  s0 sum dy*(A dx)   s1 sum dy^2      s2 dual objective (rows)  s3 sum (yt-y0)^2  s4 sum yt^2
+//  m12 max unscaled row violation
+__global__ __launch_bounds__(kBlock) void k_chk_rows(int64_t m, SpMat A, const double* __restrict__ x,
+                                                     const double* __restrict__ xt, const double* __restrict__ y,
+                                                     const double* __restrict__ yt, const double* __restrict__ y0,
+                                                     const double* __restrict__ lo, const double* __restrict__ hi,
+                                                     const double* __restrict__ dr, double* __restrict__ partials) {
+    ChkAcc a; a.init();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+        double axt = 0.0, axk = 0.0;
+        for (int64_t e = A.ptr[i]; e < A.ptr[i + 1]; ++e) {
+            const int c = A.idx[e];
+            const double v = A.val[e];
+            axt += v * xt[c];
+            axk += v * x[c];
+        }
+        const double ytv = yt[i], dy = ytv - y[i];
+        a.s[0] += dy * (axt - axk);
+        a.s[1] += dy * dy;
+        if (ytv > 0.0) a.s[2] += lo[i] * ytv;        // lo finite whenever yt > 0 (prox keeps y <= 0 otherwise)
+        else if (ytv < 0.0) a.s[2] += hi[i] * ytv;
+        const double d0 = ytv - y0[i];
+        a.s[3] += d0 * d0;
+        a.s[4] += ytv * ytv;
+        const double viol = fmax(fmax(lo[i] - axt, axt - hi[i]), 0.0) / dr[i];
+        a.s[12] = fmax(a.s[12], viol);
+    }
+    chk_block_store(a, partials);
+}
+
+//  s5 sum dx^2  s6 primal objective  s7 dual objective (bounds)  s8 sum (xt-x0)^2  s9 sum xt^2
+//  m13 max unscaled dual residual (reduced cost not absorbable by a finite bound)
+__global__ __launch_bounds__(kBlock) void k_chk_cols(int64_t n, SpMat AT, const double* __restrict__ x,
+                                                     const double* __restrict__ xt, const double* __restrict__ x0,
+                                                     const double* __restrict__ yt, const double* __restrict__ c,
+                                                     const double* __restrict__ l, const double* __restrict__ u,
+                                                     const double* __restrict__ dc, double* __restrict__ partials) {
+    ChkAcc a; a.init();
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) {
+        double aty = 0.0;
+        for (int64_t e = AT.ptr[j]; e < AT.ptr[j + 1]; ++e) aty += AT.val[e] * yt[AT.idx[e]];
+        const double xtv = xt[j], dx = xtv - x[j];
+        a.s[5] += dx * dx;
+        a.s[6] += c[j] * xtv;
+        const double r = c[j] - aty;
+        double bad = 0.0;
+        if (r > 0.0) { if (isfinite(l[j])) a.s[7] += l[j] * r; else bad = r; }
+        else if (r < 0.0) { if (isfinite(u[j])) a.s[7] += u[j] * r; else bad = -r; }
+        const double d0 = xtv - x0[j];
+        a.s[8] += d0 * d0;
+        a.s[9] += xtv * xtv;
+        a.s[13] = fmax(a.s[13], bad / dc[j]);
+    }
+    chk_block_store(a, partials);
+}
+
+// ---------------------------------------------------------- diagonal scaling ------
+// Ruiz / Pock-Chambolle passes on the UNSCALED matrix with the current dr, dc:
+//   mode 0: out_i = dr_i * max_e |a_e| dc_col(e)     mode 1: out_i = dr_i * sum_e |a_e| dc_col(e)
+// (the same kernel serves columns through the CSC mirror with the roles of dr/dc swapped)
+__global__ __launch_bounds__(kBlock) void k_scale_stat(int64_t m, const int64_t* __restrict__ ptr,
+                                                       const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                       const double* __restrict__ dself, const double* __restrict__ dother,
+                                                       int mode, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    double acc = 0.0;
+    for (int64_t e = ptr[i]; e < ptr[i + 1]; ++e) {
+        const double v = fabs(val[e]) * dother[idx[e]];
+        acc = mode ? acc + v : fmax(acc, v);
+    }
+    out[i] = dself[i] * acc;
+}
+__global__ __launch_bounds__(kBlock) void k_scale_apply(int64_t m, double* __restrict__ d, const double* __restrict__ stat) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const double s = stat[i];
+    if (s > 0.0 && isfinite(s)) d[i] /= sqrt(s);
+}
+// sval_e = dself_i * a_e * dother_idx(e)
+__global__ __launch_bounds__(kBlock) void k_scale_vals(int64_t m, const int64_t* __restrict__ ptr,
+                                                       const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                       const double* __restrict__ dself, const double* __restrict__ dother,
+                                                       double* __restrict__ sval) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const double di = dself[i];
+    for (int64_t e = ptr[i]; e < ptr[i + 1]; ++e) sval[e] = di * val[e] * dother[idx[e]];
+}
+
+// scaled problem vectors
+//   mode 0 (LP):        ch = s c dc,  lh = l/dc, uh = u/dc, xh = clip(x/dc)
+//   mode 1 (recession): ch = s c dc,  box = finite? 0 : -+scale_j  (oracle/lp.py recession_ray)
+__global__ __launch_bounds__(kBlock) void k_prep_cols(int64_t n, const double* __restrict__ c, const double* __restrict__ l,
+                                                      const double* __restrict__ u, const double* __restrict__ dc,
+                                                      const double* __restrict__ x, const double* __restrict__ box,
+                                                      double sgn, int mode, double* __restrict__ ch,
+                                                      double* __restrict__ lh, double* __restrict__ uh,
+                                                      double* __restrict__ xh) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    const double d = dc[j];
+    ch[j] = sgn * c[j] * d;
+    double lo = l[j], hi = u[j];
+    if (mode == 1) {
+        const double b = box ? box[j] : 1.0;
+        lo = isfinite(lo) ? 0.0 : -b;
+        hi = isfinite(hi) ? 0.0 : b;
+    }
+    lh[j] = lo / d;
+    uh[j] = hi / d;
+    xh[j] = clampd((mode == 1 ? 0.0 : x[j]) / d, lo / d, hi / d);
+}
+__global__ __launch_bounds__(kBlock) void k_prep_rows(int64_t m, const double* __restrict__ lo, const double* __restrict__ hi,
+                                                      const double* __restrict__ dr, const double* __restrict__ y, int mode,
+                                                      double* __restrict__ loh, double* __restrict__ hih,
+                                                      double* __restrict__ yh) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    double a = lo[i], b = hi[i];
+    if (a != a) a = -__builtin_inf();   // NaN bound = vacuous side (oracle/lp.py add_rows)
+    if (b != b) b = __builtin_inf();
+    if (mode == 1) {
+        a = isfinite(a) ? 0.0 : -__builtin_inf();
+        b = isfinite(b) ? 0.0 : __builtin_inf();
+    }
+    const double d = dr[i];
+    loh[i] = a * d;
+    hih[i] = b * d;
+    yh[i] = (mode == 1) ? 0.0 : y[i] / d;
+}
+__global__ __launch_bounds__(kBlock) void k_unscale(int64_t n, const double* __restrict__ zh, const double* __restrict__ d,
+                                                    double* __restrict__ z) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) z[i] = zh[i] * d[i];
+}
+
+// ---------------------------------------------------------- generic vector ops ----
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_spmv(int64_t m, SpMat A, const double* __restrict__ v, double* __restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (i >= m) return;
+    double acc = 0.0;
+    for (int64_t e = A.ptr[i] + lane; e < A.ptr[i + 1]; e += G) acc += A.val[e] * v[A.idx[e]];
+    acc = group_sum<G>(acc);
+    if (lane == 0) out[i] = acc;
+}
+// partials[b] = sum over the block's grid-stride share of a_i * b_i  (b may alias a)
+__global__ __launch_bounds__(kBlock) void k_dot_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                                        double* __restrict__ partials) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) acc += a[i] * b[i];
+    __shared__ double sh[kBlock / 64];
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = 0.0;
+        for (int k = 0; k < kBlock / 64; ++k) v += sh[k];
+        partials[blockIdx.x] = v;
+    }
+}
+__global__ void k_sum_final(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        double v = 0.0;
+        for (int b = 0; b < nblocks; ++b) v += partials[b];
+        out[0] = v;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_scale_vec(int64_t n, double* __restrict__ z, double s) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) z[i] *= s;
+}
+__global__ __launch_bounds__(kBlock) void k_fill(int64_t n, double* __restrict__ z, double v) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) z[i] = v;
+}
+__global__ __launch_bounds__(kBlock) void k_axpy_scaled(int64_t n, const double* __restrict__ a, double s, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = a[i] * s;
+}
+
+// ---------------------------------------------------------- CSC mirror build ------
+// key = (col << 32) | row, value = entry index; a radix sort by key orders every column
+// by row index, so the column sums are summed in a fixed order (deterministic).
+__global__ __launch_bounds__(kBlock) void k_csc_keys(int64_t m, const int64_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col, uint64_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ vals, int64_t* __restrict__ colcount) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+        const uint32_t c = (uint32_t)col[e];
+        keys[e] = ((uint64_t)c << 32) | (uint64_t)(uint32_t)i;
+        vals[e] = (uint32_t)e;
+        atomicAdd(reinterpret_cast<unsigned long long*>(&colcount[c]), 1ULL);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_csc_gather(int64_t nnz, const uint64_t* __restrict__ keys,
+                                                       const uint32_t* __restrict__ perm, const double* __restrict__ val,
+                                                       int32_t* __restrict__ crow, double* __restrict__ cval) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= nnz) return;
+    crow[p] = (int32_t)(keys[p] & 0xffffffffULL);
+    cval[p] = val[perm[p]];
+}
+
+// recession-LP box of the epigraph variable: 1 + max_r sum_{j != aux} |a_rj| / |a_r,aux|
+__global__ __launch_bounds__(kBlock) void k_aux_box(int64_t m, const int64_t* __restrict__ rowptr,
+                                                    const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                    int32_t aux, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    double tot = 0.0, av = 0.0;
+    for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+        const double a = fabs(val[e]);
+        tot += a;
+        if (col[e] == aux) av += a;
+    }
+    if (av > 0.0) atomic_max_nonneg(out, (tot - av) / av);
+}
+
+}  // namespace ktn

@@ -1,0 +1,238 @@
+"""Seeded synthetic convex NLPs with a planted optimum.
+
+The reference ships no benchmark instances; these are
+the instances BASELINE.json's configs are measured on.  Everything is plain
+numpy arrays in the layout `ktn_load_problem` takes (include/katana_hip.h), so
+the very same arrays feed the HIP path, the CPU oracle and the fixtures.
+
+    variables   x in [-B, B]^n                        (box => LP never unbounded)
+    linear rows a_r'x <= a_r'xhat + slack             m_lin rows, 8 nnz each
+    NL rows     g_i(x) = sum_{j in S_i} atom_ij(x_j) - r_i <= 0,   |S_i| = k
+                  quad family :  a (x - c)^2
+                  explog family: w exp(a x)  (half of S_i)  and  -v log(x + B + 1)
+    objective   c = -sum_{i active} lambda_i grad g_i(xhat)   => xhat is KKT-optimal,
+                optimum c'xhat known in closed form (no Ipopt needed)
+
+A fraction `active_frac` of the NL rows is active at xhat (g_i(xhat) = 0), the
+rest have slack U(0.1, 1).
+
+`vertex=True` (default; deviation from SURVEY.md section 8d, see DESIGN.md
+"Instances"): xhat is made a NON-DEGENERATE VERTEX of the feasible set.  A
+fraction `lin_active_frac` of the linear rows is active too, every active row
+is matched to a private pivot column, and every non-pivot variable sits on one
+of its bounds (l_j = xhat_j or u_j = xhat_j) with a positive multiplier, so
+that #active constraints = n with a structurally nonsingular active Jacobian.
+Kelley's method then has its Newton-like local convergence (tens of ECP
+iterations).  With vertex=False the optimum lies on a smooth face, where the
+cutting-plane method needs thousands of iterations already at n ~ 20 (the
+reference's own test/misc.jl behaviour) -- that regime is covered by the KATs.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+ATOM_LIN, ATOM_QUAD, ATOM_EXP, ATOM_NEGLOG = 0, 1, 2, 3
+
+# BASELINE.json configs (k = nnz per nonlinear row fixed in SURVEY.md section 8)
+CONFIGS = {
+    "cfg2": dict(n=10_000, m_nl=1_000, k=64, family="quad"),
+    "cfg3": dict(n=100_000, m_nl=10_000, k=32, family="explog"),
+    "cfg3_hbm": dict(n=100_000, m_nl=10_000, k=2048, family="explog"),
+    "cfg4": dict(n=100_000, m_nl=1_000_000, k=32, family="explog"),
+    "cfg5_one": dict(n=1_000, m_nl=100, k=16, family="explog"),
+}
+
+
+@dataclass
+class SeparableInstance:
+    n: int
+    l_var: np.ndarray
+    u_var: np.ndarray
+    sense: str
+    # all constraint rows (linear rows first), CSR with per-entry atoms
+    rowptr: np.ndarray
+    col: np.ndarray
+    kind: np.ndarray
+    p0: np.ndarray
+    p1: np.ndarray
+    rconst: np.ndarray
+    l_constr: np.ndarray
+    u_constr: np.ndarray
+    # separable objective
+    obj_col: np.ndarray
+    obj_kind: np.ndarray
+    obj_p0: np.ndarray
+    obj_p1: np.ndarray
+    obj_const: float
+    # planted solution
+    xhat: np.ndarray
+    opt_obj: float
+    m_lin: int
+    m_nl: int
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def num_constr(self):
+        return len(self.rowptr) - 1
+
+
+def _distinct_sorted_cols(rng, rows, k, n):
+    """k distinct, ascending column indices per row (vectorised)."""
+    base = np.sort(rng.integers(0, n - k + 1, size=(rows, k)), axis=1)
+    return base + np.arange(k)[None, :]
+
+
+def atom_value_deriv(kind, p0, p1, xv):
+    val = np.empty_like(xv)
+    der = np.empty_like(xv)
+    m = kind == ATOM_LIN
+    val[m], der[m] = p0[m] * xv[m], p0[m]
+    m = kind == ATOM_QUAD
+    d = xv[m] - p1[m]
+    val[m], der[m] = p0[m] * d * d, 2.0 * p0[m] * d
+    m = kind == ATOM_EXP
+    e = p0[m] * np.exp(p1[m] * xv[m])
+    val[m], der[m] = e, p1[m] * e
+    m = kind == ATOM_NEGLOG
+    s = xv[m] + p1[m]
+    val[m], der[m] = -p0[m] * np.log(s), -p0[m] / s
+    return val, der
+
+
+def make_instance(n, m_nl, k, family="explog", seed=0, m_lin=None, lin_nnz=8, B=10.0,
+                  active_frac=0.05, objective="linear", vertex=True, lin_active_frac=0.3,
+                  pivot_boost=True):
+    rng = np.random.default_rng(seed)
+    m_lin = n // 2 if m_lin is None else m_lin
+    lin_nnz = min(lin_nnz, n)
+    k = min(k, n)
+    xhat = rng.uniform(-1.0, 1.0, size=n)
+
+    # ---- structure, active sets, pivot matching -----------------------------
+    lcol2 = _distinct_sorted_cols(rng, m_lin, lin_nnz, n)
+    ncol2 = _distinct_sorted_cols(rng, m_nl, k, n)
+    active = rng.random(m_nl) < active_frac
+    if m_nl and not active.any():
+        active[0] = True
+    lin_active = np.zeros(m_lin, dtype=bool)
+    used = np.zeros(n, dtype=bool)
+    lin_pivot = np.full(m_lin, -1)      # position (0..lin_nnz-1) of the pivot entry in the row
+    nl_pivot = np.full(m_nl, -1)
+    if vertex:
+        lin_active = rng.random(m_lin) < lin_active_frac
+        cand = [(0, r) for r in np.nonzero(lin_active)[0]] + [(1, i) for i in np.nonzero(active)[0]]
+        for idx in rng.permutation(len(cand)):
+            which, r = cand[idx]
+            cols_r = lcol2[r] if which == 0 else ncol2[r]
+            free = np.nonzero(~used[cols_r])[0]
+            if len(free):
+                pos = free[rng.integers(len(free))]
+                used[cols_r[pos]] = True
+                if which == 0:
+                    lin_pivot[r] = pos
+                else:
+                    nl_pivot[r] = pos
+            elif which == 0:
+                lin_active[r] = False
+            else:
+                active[r] = False
+
+    # ---- linear block ------------------------------------------------------
+    lval2 = rng.standard_normal((m_lin, lin_nnz))
+    if vertex and pivot_boost:
+        ra = np.nonzero(lin_active)[0]
+        lval2[ra, lin_pivot[ra]] = np.sign(lval2[ra, lin_pivot[ra]]) * rng.uniform(2.0, 4.0, size=len(ra))
+    lcol, lval = lcol2.reshape(-1), lval2.reshape(-1)
+    lrow = np.repeat(np.arange(m_lin), lin_nnz)
+    ax = np.bincount(lrow, weights=lval * xhat[lcol], minlength=m_lin)
+    lin_ub = ax + np.where(lin_active, 0.0, rng.uniform(0.1, 1.0, size=m_lin))
+
+    # ---- nonlinear block ---------------------------------------------------
+    if family == "quad":
+        nkind = np.full((m_nl, k), ATOM_QUAD, dtype=np.uint8)
+        np0 = rng.uniform(0.5, 2.0, size=(m_nl, k))
+        np1 = rng.standard_normal((m_nl, k))
+        if vertex and pivot_boost:
+            # pivot atom: derivative 2a(x-c) of magnitude U(4,8) -> dominates the row's basis entries
+            ra = np.nonzero(active)[0]
+            xa = xhat[ncol2[ra, nl_pivot[ra]]]
+            np0[ra, nl_pivot[ra]] = 2.0
+            np1[ra, nl_pivot[ra]] = xa - rng.choice([-1.0, 1.0], size=len(ra)) * rng.uniform(1.0, 2.0, size=len(ra))
+    elif family == "explog":
+        nkind = np.full((m_nl, k), ATOM_EXP, dtype=np.uint8)
+        neg = rng.random((m_nl, k)) < 0.5
+        np0 = rng.uniform(0.1, 1.0, size=(m_nl, k))
+        np1 = rng.uniform(-0.5, 0.5, size=(m_nl, k))
+        if vertex and pivot_boost:
+            # pivot atom: w exp(a x) with |d/dx| = U(1,2) at xhat
+            ra = np.nonzero(active)[0]
+            pa = nl_pivot[ra]
+            neg[ra, pa] = False
+            a = rng.choice([-0.5, 0.5], size=len(ra))
+            np1[ra, pa] = a
+            np0[ra, pa] = rng.uniform(1.0, 2.0, size=len(ra)) / (0.5 * np.exp(a * xhat[ncol2[ra, pa]]))
+        nkind[neg] = ATOM_NEGLOG
+        np1[neg] = B + 1.0
+    else:
+        raise ValueError(family)
+    ncol, nkind, np0, np1 = ncol2.reshape(-1), nkind.reshape(-1), np0.reshape(-1), np1.reshape(-1)
+    nrow = np.repeat(np.arange(m_nl), k)
+    val, der = atom_value_deriv(nkind, np0, np1, xhat[ncol])
+    gx = np.bincount(nrow, weights=val, minlength=m_nl)
+    slack = np.where(active, 0.0, rng.uniform(0.1, 1.0, size=m_nl))
+    r = gx + slack
+    lam = np.where(active, rng.uniform(0.5, 1.5, size=m_nl), 0.0)
+    mu = np.where(lin_active, rng.uniform(0.5, 1.5, size=m_lin), 0.0)
+    l_var = np.full(n, -B)
+    u_var = np.full(n, B)
+    c = -np.bincount(ncol, weights=(lam[nrow] * der), minlength=n)
+    if vertex:
+        at_bound = ~used
+        lower = at_bound & (rng.random(n) < 0.5)
+        upper = at_bound & ~lower
+        l_var[lower] = xhat[lower]
+        u_var[upper] = xhat[upper]
+        nu = rng.uniform(0.5, 1.5, size=n)
+        c -= np.bincount(lcol, weights=(mu[lrow] * lval), minlength=n)
+        c[lower] += nu[lower]
+        c[upper] -= nu[upper]
+
+    # ---- objective ---------------------------------------------------------
+    if objective == "linear":
+        nz = np.nonzero(c)[0]
+        obj_col, obj_kind = nz, np.zeros(len(nz), dtype=np.uint8)
+        obj_p0, obj_p1 = c[nz], np.zeros(len(nz))
+        opt = float(c @ xhat)
+    elif objective == "quad":
+        # f(x) = sum_j 0.5 d_j (x_j - x0_j)^2 with grad f(xhat) = c  (dense epigraph row)
+        dj = rng.uniform(0.5, 2.0, size=n)
+        x0 = xhat - c / dj
+        obj_col, obj_kind = np.arange(n), np.full(n, ATOM_QUAD, dtype=np.uint8)
+        obj_p0, obj_p1 = 0.5 * dj, x0
+        opt = float(np.sum(0.5 * dj * (xhat - x0) ** 2))
+    else:
+        raise ValueError(objective)
+
+    rowptr = np.concatenate([np.arange(m_lin + 1) * lin_nnz,
+                             m_lin * lin_nnz + np.arange(1, m_nl + 1) * k]).astype(np.int64)
+    inst = SeparableInstance(
+        n=n, l_var=l_var, u_var=u_var, sense="Min",
+        rowptr=rowptr,
+        col=np.concatenate([lcol, ncol]).astype(np.int32),
+        kind=np.concatenate([np.zeros(len(lcol), dtype=np.uint8), nkind]).astype(np.uint8),
+        p0=np.concatenate([lval, np0]), p1=np.concatenate([np.zeros(len(lcol)), np1]),
+        rconst=np.concatenate([np.zeros(m_lin), -r]),
+        l_constr=np.full(m_lin + m_nl, -np.inf),
+        u_constr=np.concatenate([lin_ub, np.zeros(m_nl)]),
+        obj_col=obj_col.astype(np.int32), obj_kind=obj_kind, obj_p0=obj_p0, obj_p1=obj_p1, obj_const=0.0,
+        xhat=xhat, opt_obj=opt, m_lin=m_lin, m_nl=m_nl,
+        meta=dict(n=n, m_nl=m_nl, k=k, family=family, seed=seed, m_lin=m_lin, lin_nnz=lin_nnz, B=B,
+                  active_frac=active_frac, objective=objective, n_active=int(active.sum()),
+                  vertex=bool(vertex), n_lin_active=int(lin_active.sum())))
+    return inst
+
+
+def make_config(name, seed=0, **overrides):
+    kw = dict(CONFIGS[name])
+    kw.update(overrides)
+    return make_instance(seed=seed, **kw)

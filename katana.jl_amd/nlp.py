@@ -1,0 +1,132 @@
+"""Device-evaluable NLP descriptions: what `d::AbstractNLPEvaluator` is to the reference's
+loadproblem! (src/model.jl:86).  An NLPDescription owns the numpy arrays behind a
+`ktn_nlp_desc` (include/katana_hip.h) and answers the structural queries the reference asks
+its evaluator (jac_structure, isconstrlinear, isobjlinear); values and derivatives are
+computed on the device only."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .expr import Expr
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype)) if a is not None and a.size else C.POINTER(ctype)()
+
+
+class NLPDescription:
+    def __init__(self, num_var, rowptr, col, row_kind, row_linear, rconst, atom_kind, p0, p1,
+                 tape_ptr=None, tape_op=None, tape_arg=None,
+                 obj_linear=True, obj_kind=L.ROW_SEP, obj_col=None, obj_atom_kind=None, obj_p0=None, obj_p1=None,
+                 obj_const=0.0, obj_tape_op=None, obj_tape_arg=None):
+        i64, i32, u8, f64 = np.int64, np.int32, np.uint8, np.float64
+        self.num_var = int(num_var)
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=i64)
+        self.num_constr = len(self.rowptr) - 1
+        self.col = np.ascontiguousarray(col, dtype=i32)
+        nnz = len(self.col)
+        self.row_kind = np.ascontiguousarray(row_kind, dtype=u8)
+        self.row_linear = np.ascontiguousarray(row_linear, dtype=u8)
+        self.rconst = np.ascontiguousarray(rconst, dtype=f64)
+        self.atom_kind = np.ascontiguousarray(atom_kind if atom_kind is not None else np.zeros(nnz), dtype=u8)
+        self.p0 = np.ascontiguousarray(p0 if p0 is not None else np.zeros(nnz), dtype=f64)
+        self.p1 = np.ascontiguousarray(p1 if p1 is not None else np.zeros(nnz), dtype=f64)
+        self.tape_ptr = np.ascontiguousarray(tape_ptr if tape_ptr is not None else np.zeros(self.num_constr + 1), dtype=i64)
+        self.tape_op = np.ascontiguousarray(tape_op if tape_op is not None else [], dtype=i32)
+        self.tape_arg = np.ascontiguousarray(tape_arg if tape_arg is not None else [], dtype=f64)
+        self.obj_linear = bool(obj_linear)
+        self.obj_kind = int(obj_kind)
+        self.obj_col = np.ascontiguousarray(obj_col if obj_col is not None else [], dtype=i32)
+        k = len(self.obj_col)
+        self.obj_atom_kind = np.ascontiguousarray(obj_atom_kind if obj_atom_kind is not None else np.zeros(k), dtype=u8)
+        self.obj_p0 = np.ascontiguousarray(obj_p0 if obj_p0 is not None else np.zeros(k), dtype=f64)
+        self.obj_p1 = np.ascontiguousarray(obj_p1 if obj_p1 is not None else np.zeros(k), dtype=f64)
+        self.obj_const = float(obj_const)
+        self.obj_tape_op = np.ascontiguousarray(obj_tape_op if obj_tape_op is not None else [], dtype=i32)
+        self.obj_tape_arg = np.ascontiguousarray(obj_tape_arg if obj_tape_arg is not None else [], dtype=f64)
+        assert len(self.row_kind) == self.num_constr and len(self.row_linear) == self.num_constr
+        assert len(self.rconst) == self.num_constr and len(self.p0) == nnz and len(self.p1) == nnz
+
+    # ---- the structural part of the MathProgBase evaluator interface --------------------
+    def isobjlinear(self):
+        return self.obj_linear
+
+    def isconstrlinear(self, i):
+        return bool(self.row_linear[i])
+
+    def jac_structure(self):
+        rows = np.repeat(np.arange(self.num_constr), np.diff(self.rowptr))
+        return rows, self.col
+
+    def features_available(self):
+        return ["Grad", "Jac"]
+
+    def c_struct(self):
+        d = L.KtnNlpDesc()
+        d.num_var, d.num_constr = self.num_var, self.num_constr
+        d.rowptr, d.col = _ptr(self.rowptr, C.c_int64), _ptr(self.col, C.c_int32)
+        d.row_kind, d.row_linear = _ptr(self.row_kind, C.c_uint8), _ptr(self.row_linear, C.c_uint8)
+        d.rconst, d.atom_kind = _ptr(self.rconst, C.c_double), _ptr(self.atom_kind, C.c_uint8)
+        d.p0, d.p1 = _ptr(self.p0, C.c_double), _ptr(self.p1, C.c_double)
+        d.tape_ptr, d.tape_op, d.tape_arg = (_ptr(self.tape_ptr, C.c_int64), _ptr(self.tape_op, C.c_int32),
+                                             _ptr(self.tape_arg, C.c_double))
+        d.obj_linear, d.obj_kind, d.obj_nnz = int(self.obj_linear), self.obj_kind, len(self.obj_col)
+        d.obj_col, d.obj_atom_kind = _ptr(self.obj_col, C.c_int32), _ptr(self.obj_atom_kind, C.c_uint8)
+        d.obj_p0, d.obj_p1, d.obj_const = _ptr(self.obj_p0, C.c_double), _ptr(self.obj_p1, C.c_double), self.obj_const
+        d.obj_tape_len = len(self.obj_tape_op)
+        d.obj_tape_op, d.obj_tape_arg = _ptr(self.obj_tape_op, C.c_int32), _ptr(self.obj_tape_arg, C.c_double)
+        return d
+
+
+def SeparableNLP(inst):
+    """NLPDescription of a katana_jl_amd.instances.SeparableInstance (or any object with the
+    same array attributes)."""
+    rows = np.repeat(np.arange(len(inst.rowptr) - 1), np.diff(inst.rowptr))
+    nonlin = np.bincount(rows[np.asarray(inst.kind) != L.ATOM_LIN], minlength=len(inst.rowptr) - 1)
+    m = len(inst.rowptr) - 1
+    return NLPDescription(
+        inst.n, inst.rowptr, inst.col, np.zeros(m, dtype=np.uint8), (nonlin == 0).astype(np.uint8), inst.rconst,
+        inst.kind, inst.p0, inst.p1,
+        obj_linear=bool(np.all(np.asarray(inst.obj_kind) == L.ATOM_LIN)), obj_kind=L.ROW_SEP,
+        obj_col=inst.obj_col, obj_atom_kind=inst.obj_kind, obj_p0=inst.obj_p0, obj_p1=inst.obj_p1,
+        obj_const=inst.obj_const)
+
+
+def ExprNLP(num_var, objective, constraints, constr_linear=None, obj_linear=None):
+    """NLPDescription from expressions.  Affine rows become separable rows of LIN atoms (their
+    tangent at the origin is the row itself, src/model.jl:115-118); every other row becomes a
+    tape row."""
+    rowptr, col, akind, p0, p1, rkind, rlin, rconst = [0], [], [], [], [], [], [], []
+    tptr, top, targ = [0], [], []
+    for i, e in enumerate(constraints):
+        e = Expr.wrap(e)
+        aff = e.affine()
+        declared = constr_linear[i] if constr_linear is not None else (aff is not None)
+        if aff is not None:
+            co, c0 = aff
+            for j in sorted(co):
+                col.append(j); akind.append(L.ATOM_LIN); p0.append(co[j]); p1.append(0.0)
+            rkind.append(L.ROW_SEP); rconst.append(c0)
+        else:
+            for j in e.variables():
+                col.append(j); akind.append(0); p0.append(0.0); p1.append(0.0)
+            o, a = e.tape()
+            top.extend(o.tolist()); targ.extend(a.tolist())
+            rkind.append(L.ROW_TAPE); rconst.append(0.0)
+        rlin.append(1 if declared else 0)
+        rowptr.append(len(col)); tptr.append(len(top))
+    objective = Expr.wrap(objective)
+    oaff = objective.affine()
+    is_lin = obj_linear if obj_linear is not None else (oaff is not None)
+    kw = {}
+    if oaff is not None:
+        co, c0 = oaff
+        js = sorted(co)
+        kw = dict(obj_kind=L.ROW_SEP, obj_col=js, obj_atom_kind=np.zeros(len(js)), obj_p0=[co[j] for j in js],
+                  obj_p1=np.zeros(len(js)), obj_const=c0)
+    else:
+        o, a = objective.tape()
+        kw = dict(obj_kind=L.ROW_TAPE, obj_tape_op=o, obj_tape_arg=a)
+    return NLPDescription(num_var, rowptr, col, rkind, rlin, rconst, akind, p0, p1, tptr, top, targ,
+                          obj_linear=is_lin, **kw)

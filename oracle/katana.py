@@ -143,7 +143,7 @@ def glpk_bound_vertex(l_var, u_var):
 # model.jl
 # --------------------------------------------------------------------------
 class KatanaNonlinearModel:
-    def __init__(self, params=None, fast=False, lp_threads=1, vis_data=False):
+    def __init__(self, params=None, fast=False, lp_threads=1, vis_data=False, lp_factory=None):
         self.params = params if params is not None else KatanaModelParams()
         self.status = "None"                 # src/model.jl:44
         self.objval = float("nan")
@@ -153,6 +153,7 @@ class KatanaNonlinearModel:
         self.soltime = 0.0
         self.fast = fast
         self.lp_threads = lp_threads
+        self.lp_factory = lp_factory if lp_factory is not None else LinearModel
         self.vis_data = vis_data
         self.lp_sols = []
         self.linear_cuts = []
@@ -172,7 +173,7 @@ class KatanaNonlinearModel:
 
     # src/model.jl:81-173
     def loadproblem(self, num_var, num_constr, l_var, u_var, l_constr, u_constr, sense, d):
-        self.linear_model = LinearModel(threads=self.lp_threads)
+        self.linear_model = self.lp_factory(threads=self.lp_threads)
         self.linear_model.add_variables(l_var, u_var)                      # :92
         vertex = glpk_bound_vertex(l_var, u_var)                            # :93-97
         if np.any(np.asarray(l_var) > np.asarray(u_var)):
@@ -344,6 +345,8 @@ class KatanaNonlinearModel:
             with np.errstate(all="ignore"):
                 obj_delta = abs(np.float64(obj_prev - obj) / np.float64(obj))
             obj_prev = obj
+            if p.log_level > 0 and (self.iter % p.log_level == 0 or allsat):
+                print("oracle iter %d cuts %d obj %.10g lp_time %.2fs" % (self.iter, self.numcuts, obj, self.lp_time), flush=True)
             if obj_delta <= p.obj_eps:                                      # :306-308
                 break
         self.soltime = time.time() - start                                  # :311

@@ -30,10 +30,11 @@ _KINF = _hc.kHighsInf
 
 def _new_highs(threads=1):
     h = _hc._Highs()
-    h.setOptionValue("output_flag", False)
+    h.setOptionValue("output_flag", bool(__import__("os").environ.get("KTN_ORACLE_LPLOG")))
     h.setOptionValue("solver", "simplex")
     h.setOptionValue("simplex_strategy", 1)      # dual simplex, serial
-    h.setOptionValue("threads", int(threads))
+    if threads and int(threads) > 1:
+        h.setOptionValue("threads", int(threads))
     h.setOptionValue("primal_feasibility_tolerance", 1e-9)
     h.setOptionValue("dual_feasibility_tolerance", 1e-9)
     return h
@@ -130,6 +131,10 @@ class LinearModel:
             self.h.run()
             st = self.h.getModelStatus()
         self.simplex_iters += int(self.h.getInfo().simplex_iteration_count)
+        # cache: HiGHS drops solution/info as soon as rows are appended, while
+        # the reference reads x* and the objective after adding cuts (model.jl:265,287)
+        self._x = np.array(self.h.getSolution().col_value, dtype=np.float64)
+        self._obj = float(self.h.getInfo().objective_function_value)
         if st == _hc.HighsModelStatus.kOptimal:
             return "Optimal"
         if st == _hc.HighsModelStatus.kUnbounded:
@@ -139,10 +144,10 @@ class LinearModel:
         return "Error"
 
     def getsolution(self):
-        return np.array(self.h.getSolution().col_value, dtype=np.float64)
+        return self._x.copy()
 
     def getobjval(self):
-        return float(self.h.getInfo().objective_function_value)
+        return self._obj
 
     def getunboundedray(self, aux=None):
         """`aux`: index of the epigraph variable (or None).  Its box in the
