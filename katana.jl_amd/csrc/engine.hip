@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <limits>
 #include <map>
@@ -44,6 +45,14 @@ __global__ __launch_bounds__(kBlock) void k_finite_sq_partial(int64_t n, const d
         for (int k = 0; k < kBlock / 64; ++k) v += sh[k];
         partials[blockIdx.x] = v;
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_hash_fill(int64_t n, double* __restrict__ z) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint64_t h = (uint64_t)i * 0x9E3779B97F4A7C15ULL + 0xD1B54A32D192ED03ULL;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+    z[i] = 0.25 + (double)(h >> 11) * (1.0 / 9007199254740992.0);   // in [0.25, 1.25)
 }
 
 static inline int pick_group(double avg_len) {
@@ -731,8 +740,10 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
     // step size: power iteration on A^'A^
     double smax = 0.0;
     if (m > 0 && NNZ > 0) {
-        LAUNCH_1(k_fill, n, stream, n, pv.p, 1.0 / std::sqrt((double)n));
-        double vnorm = 1.0;
+        // deterministic pseudo-random start (a constant vector can be orthogonal to every row,
+        // e.g. the single epigraph cut t - x >= 1)
+        LAUNCH_1(k_hash_fill, n, stream, n, pv.p);
+        double vnorm = std::sqrt(dev_dot(n, pv.p, pv.p));
         for (int it = 0; it < 20; ++it) {
             LAUNCH_G(grp_rows, k_spmv, m, stream, m, A, pv.p, pw.p);
             LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, pw.p, xbar.p);
@@ -743,6 +754,7 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
             vnorm = 1.0;
         }
     }
+    if (!(smax > 0.0) && NNZ > 0) smax = std::sqrt(dev_dot(NNZ, r_sval.p, r_sval.p));   // ||A||_2 <= ||A||_F
     const double eta = 0.998 / std::max(smax, 1e-12);
     const double nc2 = dev_dot(n, ch.p, ch.p);
     const double nb2 = (m > 0) ? dev_finite_sq(m, loh.p) + dev_finite_sq(m, hih.p) : 0.0;
@@ -758,6 +770,7 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
     const double kx_bytes = (double)NNZ * 12 + 8.0 * (n + 1) + 8.0 * 7 * n + 8.0 * m;
     int64_t k = 0, it = 0;
     double r0 = 0.0, r_prev = 0.0;
+    static const bool dbg_lp = std::getenv("KTN_DEBUG_LP") != nullptr;
     R.status = KTN_STATUS_USERLIMIT;
     const int64_t max_it = prm.lp_max_iter;
     const int chk = std::max(1, prm.lp_check_every);
@@ -802,6 +815,8 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
         const double r = std::sqrt(std::max(r2, 0.0));
         const double gap = std::fabs(pobj - dobj) / (1.0 + std::fabs(pobj) + std::fabs(dobj));
         if (k == 0) { r0 = r; r_prev = r; }
+        if (dbg_lp) std::fprintf(stderr, "[lp mode %d] it %7lld k %6lld r %.3e pviol %.3e dres %.3e gap %.3e pobj %.10g dobj %.10g om %.3g eta %.3g\n",
+                                 mode, (long long)it, (long long)k, r, pviol, dres, gap, pobj, dobj, om, eta);
         R.pobj = pobj; R.dobj = dobj; R.row_viol = pviol; R.gap = gap;
         const bool done = (pviol <= tol_p) && (gap <= tol_g) && (dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2)));
         if (done || !(r == r)) {

@@ -1,0 +1,62 @@
+"""Test helpers shared by the CPU and GPU tiers."""
+import numpy as np
+
+from oracle.evaluators import SeparableNLPEvaluator, SexprNLPEvaluator
+from oracle.katana import KatanaModelParams, KatanaNonlinearModel as OracleModel
+
+
+def oracle_evaluator(inst):
+    return SeparableNLPEvaluator(inst.n, inst.rowptr, inst.col, inst.kind, inst.p0, inst.p1, inst.rconst,
+                                 inst.obj_col, inst.obj_kind, inst.obj_p0, inst.obj_p1, inst.obj_const)
+
+
+def oracle_solve_instance(inst, fast=True, **params):
+    d = oracle_evaluator(inst)
+    om = OracleModel(KatanaModelParams(**params), fast=fast)
+    om.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense, d)
+    om.optimize()
+    return om
+
+
+def oracle_solve_kat(m, **kw):
+    n = len(m["vars"])
+    d = SexprNLPEvaluator(n, m["objective"], [c["expr"] for c in m["constraints"]],
+                          [c["linear"] for c in m["constraints"]], m["objective_linear"])
+    om = OracleModel(KatanaModelParams(), **kw)
+    om.loadproblem(n, len(m["constraints"]), [v["lb"] for v in m["vars"]], [v["ub"] for v in m["vars"]],
+                   [c["lb"] for c in m["constraints"]], [c["ub"] for c in m["constraints"]], m["sense"], d)
+    om.optimize()
+    return om
+
+
+def hip_model_from_kat(ktn, m, **solver_kw):
+    M = ktn.Model(solver=ktn.KatanaSolver(log_level=0, **solver_kw))
+    for v in m["vars"]:
+        M.variable(v["lb"], v["ub"])
+    M.objective(m["sense"], ktn.from_sexpr(m["objective"]), linear=m["objective_linear"])
+    for c in m["constraints"]:
+        M.constraint((ktn.from_sexpr(c["expr"]), c["lb"], c["ub"]), linear=c["linear"])
+    return M
+
+
+def hip_load_instance(ktn, inst, **solver_kw):
+    m = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, **solver_kw))
+    m.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense,
+                  ktn.SeparableNLP(inst))
+    return m
+
+
+def max_nl_violation(inst, x):
+    """max over NL rows of g_i(x) - ub_i under the oracle's evaluator"""
+    d = oracle_evaluator(inst)
+    g = np.zeros(inst.num_constr)
+    d.eval_g(g, np.asarray(x)[:inst.n])
+    return float(np.max(g[inst.m_lin:] - inst.u_constr[inst.m_lin:])) if inst.m_nl else 0.0
+
+
+# KATs whose *solution vector / tight objective* check depends on which LP vertices the LP
+# solver happens to visit (GLPK in the reference): the stop rule g <= f_tol = 1e-6 bounds the
+# tangential error of x only by ~sqrt(2 f_tol) = 1.4e-3 on these flat optima, while the
+# reference's tests ask for 1e-3 (or rtol 1e-7 on 202_04).  Status and objective at the
+# suite-wide 1e-6 tolerance are asserted for every KAT; for these ids x is asserted at 3e-3.
+TRAJECTORY_SENSITIVE = {"105_04", "202_04", "501_02_n3", "501_02_n4", "501_02_n9"}

@@ -1,0 +1,81 @@
+"""CPU tier: host logic -- expression graphs, tapes, linearity, descriptions, instances."""
+import numpy as np
+
+import katana_jl_amd as ktn
+from kat_util import load_kats
+from oracle import sexpr
+
+
+def _eval_tape(ops, args, x):
+    """reference stack machine for the postfix tape (test-side)"""
+    L = ktn._lib
+    st = []
+    for o, a in zip(ops, args):
+        if o == L.OP_CONST: st.append(a)
+        elif o == L.OP_VAR: st.append(x[int(a)])
+        elif o in (L.OP_ADD, L.OP_SUB, L.OP_MUL, L.OP_DIV):
+            b = st.pop(); c = st.pop()
+            st.append({L.OP_ADD: c + b, L.OP_SUB: c - b, L.OP_MUL: c * b, L.OP_DIV: c / b}[o])
+        elif o == L.OP_NEG: st.append(-st.pop())
+        elif o == L.OP_POWC: st.append(st.pop() ** a)
+        else:
+            v = st.pop()
+            st.append({L.OP_EXP: np.exp, L.OP_LOG: np.log, L.OP_SQRT: np.sqrt, L.OP_SIN: np.sin, L.OP_COS: np.cos}[o](v))
+    assert len(st) == 1
+    return st[0]
+
+
+def test_tapes_of_all_kat_expressions_evaluate_like_the_oracle():
+    rng = np.random.default_rng(0)
+    for m in load_kats():
+        n = len(m["vars"])
+        x = rng.uniform(0.3, 1.7, size=n)
+        for s in [m["objective"]] + [c["expr"] for c in m["constraints"]]:
+            e = ktn.from_sexpr(s)
+            ops, args = e.tape()
+            want = sexpr.eval_grad(s, x)[0]
+            assert abs(_eval_tape(ops, args, x) - want) <= 1e-12 * max(1, abs(want))
+            assert e.variables() == sexpr.variables(s)
+            assert (e.affine() is not None) == sexpr.is_affine(s)
+
+
+def test_linearity_flags_agree_with_the_fixture():
+    for m in load_kats():
+        for c in m["constraints"]:
+            assert (ktn.from_sexpr(c["expr"]).affine() is not None) == c["linear"], m["id"]
+        assert (ktn.from_sexpr(m["objective"]).affine() is not None) == m["objective_linear"], m["id"]
+
+
+def test_affine_extraction():
+    x, y = ktn.var(0), ktn.var(1)
+    co, c0 = (3 * x - (y - 2) / 4 + 1).affine()
+    assert co == {0: 3.0, 1: -0.25} and c0 == 1.5
+    assert (x * y).affine() is None and (x ** 2).affine() is None
+
+
+def test_exprnlp_description_shapes():
+    x, y = ktn.var(0), ktn.var(1)
+    d = ktn.ExprNLP(2, -x - y, [x ** 2 + y ** 2 - 1.0, x + y - 1.2])
+    assert d.num_constr == 2 and list(d.row_kind) == [1, 0] and list(d.row_linear) == [0, 1]
+    assert d.isobjlinear() and not d.isconstrlinear(0) and d.isconstrlinear(1)
+    rows, cols = d.jac_structure()
+    assert list(rows) == [0, 0, 1, 1] and list(cols) == [0, 1, 0, 1]
+    cs = d.c_struct()
+    assert cs.num_var == 2 and cs.obj_nnz == 2
+
+
+def test_instance_generator_plants_a_kkt_vertex():
+    inst = ktn.instances.make_instance(n=600, m_nl=60, k=16, family="explog", seed=5)
+    val, der = ktn.instances.atom_value_deriv(inst.kind, inst.p0, inst.p1, inst.xhat[inst.col])
+    rows = np.repeat(np.arange(inst.num_constr), np.diff(inst.rowptr))
+    g = np.bincount(rows, weights=val, minlength=inst.num_constr) + inst.rconst
+    assert np.all(g <= inst.u_constr + 1e-12)                     # xhat feasible
+    act = np.abs(g - inst.u_constr) < 1e-12
+    free = (inst.l_var < inst.xhat - 1e-12) & (inst.u_var > inst.xhat + 1e-12)
+    assert act.sum() == free.sum() > 0                             # square active system
+    assert np.all((inst.xhat >= inst.l_var) & (inst.xhat <= inst.u_var))
+    c = np.zeros(inst.n); c[inst.obj_col] = inst.obj_p0
+    assert abs(c @ inst.xhat - inst.opt_obj) < 1e-9
+    # determinism
+    again = ktn.instances.make_instance(n=600, m_nl=60, k=16, family="explog", seed=5)
+    assert np.array_equal(again.p0, inst.p0) and np.array_equal(again.col, inst.col)

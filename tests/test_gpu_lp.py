@@ -1,0 +1,90 @@
+"""GPU tier: the LP kernels.  (1) raw reflected-Halpern PDHG iterations against a dense numpy
+statement of the same recurrences; (2) the full GPU LP solver against HiGHS on the same LP."""
+import numpy as np
+import pytest
+
+import katana_jl_amd as ktn
+from helpers import hip_load_instance
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_lp(m):
+    rowptr, col, val, lo, hi = m.lp_rows()
+    c, c0 = m.lp_objective()
+    A = np.zeros((len(lo), m.num_var))
+    for i in range(len(lo)):
+        for e in range(rowptr[i], rowptr[i + 1]):
+            A[i, col[e]] += val[e]
+    return A, c, c0, lo, hi
+
+
+def _halpern_numpy(A, c, l, u, lo, hi, x, y, eta, omega, iters):
+    tau, sigma = eta / omega, eta * omega
+    x0, y0 = x.copy(), y.copy()
+    for k in range(iters):
+        xt = np.clip(x - tau * (c - A.T @ y), l, u)
+        v = y - sigma * (A @ (2 * xt - x))
+        yt = v + sigma * np.clip(-v / sigma, lo, hi)
+        w = (k + 1) / (k + 2)
+        x = w * (2 * xt - x) + (1 - w) * x0
+        y = w * (2 * yt - y) + (1 - w) * y0
+    return x, y
+
+
+@pytest.mark.parametrize("iters", [1, 2, 50])
+def test_raw_pdhg_iterations_match_numpy(iters):
+    inst = ktn.instances.make_instance(n=300, m_nl=40, k=8, family="quad", seed=9)
+    m = hip_load_instance(ktn, inst)
+    sep = ktn.KatanaHipSeparator(m); sep.initialize()
+    sep.precompute(np.clip(inst.xhat + 0.7, inst.l_var, inst.u_var))
+    assert sep.sweep(1e-6)[0] > 0                                  # LP = linear rows + a block of cuts
+    A, c, c0, lo, hi = _dense_lp(m)
+    rng = np.random.default_rng(0)
+    x0 = rng.uniform(inst.l_var, inst.u_var)
+    y0 = rng.normal(size=len(lo)) * (np.isfinite(lo) | np.isfinite(hi))
+    y0 = np.where(np.isfinite(lo), y0, np.minimum(y0, 0.0))        # sign-feasible duals
+    eta, omega = 0.05, 1.7
+    xg, yg = m.lp_pdhg_raw(x0, y0, eta, omega, iters)
+    xn, yn = _halpern_numpy(A, c, inst.l_var, inst.u_var, lo, hi, x0, y0, eta, omega, iters)
+    assert np.max(np.abs(xg - xn)) <= 1e-11 * (1 + np.max(np.abs(xn)))
+    assert np.max(np.abs(yg - yn)) <= 1e-11 * (1 + np.max(np.abs(yn)))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_gpu_lp_matches_highs(seed):
+    from oracle.lp import LinearModel
+    inst = ktn.instances.make_instance(n=1500, m_nl=100, k=16, family="explog", seed=seed)
+    m = hip_load_instance(ktn, inst)
+    sep = ktn.KatanaHipSeparator(m); sep.initialize()
+    sep.precompute(inst.u_var * 0.999)
+    sep.sweep(1e-6)
+    status, iters = m.lp_solve(row_tol=1e-8, gap_tol=1e-8)
+    assert status == "Optimal" and iters > 0
+    rowptr, col, val, lo, hi = m.lp_rows()
+    c, c0 = m.lp_objective()
+    lm = LinearModel()
+    lm.add_variables(inst.l_var, inst.u_var)
+    lm.set_objective("Min", np.arange(inst.n), c, c0)
+    lm.add_rows(rowptr, col, val, lo, hi)
+    assert lm.solve() == "Optimal"
+    x = m.getsolution()
+    assert abs(m.getobjval() - lm.getobjval()) <= 1e-6 * max(1.0, abs(lm.getobjval()))
+    A, *_ = _dense_lp(m)
+    ax = A @ x
+    assert np.max(np.maximum(ax - hi, lo - ax)) <= 1e-7
+    assert np.all(x >= inst.l_var - 1e-12) and np.all(x <= inst.u_var + 1e-12)
+    # dual sign feasibility: y_i > 0 only where the row has a finite lower side
+    y = m.lp_duals()
+    assert np.all(y[~np.isfinite(lo)] <= 1e-12)
+
+
+def test_lp_with_no_rows_goes_to_the_bounds():
+    d = ktn.NLPDescription(3, [0], [], [], [], [], [], [], [], obj_linear=True, obj_col=[0, 1, 2],
+                           obj_atom_kind=[0, 0, 0], obj_p0=[1.0, -2.0, 0.0], obj_p1=[0, 0, 0], obj_const=0.5)
+    m = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0))
+    m.loadproblem(3, 0, [-1.0, -1.0, -1.0], [2.0, 3.0, 4.0], [], [], "Min", d)
+    assert m.optimize() == "Optimal"
+    x = m.getsolution()
+    assert x[0] == -1.0 and x[1] == 3.0 and abs(m.getobjval() - (-1.0 - 6.0 + 0.5)) < 1e-12
+    assert m.numiters() == 1 and m.numcuts() == 0

@@ -1,0 +1,73 @@
+"""CPU tier: the oracle (CPU restatement of the reference) against the reference's own
+known-answer tests, and its vectorised path against its literal path."""
+import numpy as np
+import pytest
+
+import katana_jl_amd as ktn
+from helpers import TRAJECTORY_SENSITIVE, oracle_solve_instance, oracle_solve_kat
+from kat_util import isapprox, load_kats
+
+KATS = load_kats()
+# the n-D sphere family is exercised at every second size on the CPU tier to keep it quick
+CPU_KATS = [m for m in KATS if not (m["id"].startswith("501_") and int(m["id"].split("_n")[1]) % 2 == 0
+                                    and int(m["id"].split("_n")[1]) > 4)]
+
+
+def test_fixture_covers_the_reference_suite():
+    ids = {m["id"] for m in KATS}
+    assert len(KATS) == 82
+    for must in ("basic_1", "001_01", "101_01", "105_01", "203_01", "205_01", "210_03", "501_01_n20", "501_02_n20"):
+        assert must in ids
+
+
+@pytest.mark.parametrize("m", CPU_KATS, ids=[m["id"] for m in CPU_KATS])
+def test_oracle_passes_reference_kat(m):
+    om = oracle_solve_kat(m)
+    e = m["expect"]
+    assert om.getstatus() == e["status"]
+    obj, x = om.getobjval(), om.getsolution()
+    if m["id"] in TRAJECTORY_SENSITIVE:
+        assert isapprox(obj, e["obj"], 1e-6, 1e-6)                  # suite tolerance, test/runtests.jl:16-17
+        if e["x"] is not None:
+            assert np.max(np.abs(np.asarray(x[:len(e["x"])]) - e["x"])) <= 3e-3
+    else:
+        assert isapprox(obj, e["obj"], e["obj_atol"], e["obj_rtol"])
+        if e["x"] is not None:
+            for got, want in zip(x, e["x"]):
+                assert isapprox(got, want, e["sol_atol"], e["sol_rtol"]), (list(x), e["x"])
+
+
+def test_fast_path_equals_literal_path():
+    inst = ktn.instances.make_instance(n=300, m_nl=30, k=8, family="explog", seed=1)
+    a = oracle_solve_instance(inst, fast=True)
+    b = oracle_solve_instance(inst, fast=False)
+    assert a.getstatus() == b.getstatus() == "Optimal"
+    assert a.numiters() == b.numiters() and a.getnumcuts() == b.getnumcuts()
+    assert abs(a.getobjval() - b.getobjval()) <= 1e-9 * max(1, abs(b.getobjval()))
+
+
+@pytest.mark.parametrize("family", ["explog", "quad"])
+def test_oracle_finds_planted_optimum(family):
+    inst = ktn.instances.make_instance(n=500, m_nl=50, k=16, family=family, seed=2)
+    om = oracle_solve_instance(inst)
+    assert om.getstatus() == "Optimal"
+    assert abs(om.getobjval() - inst.opt_obj) <= 1e-5 * max(1.0, abs(inst.opt_obj))
+
+
+def test_round_coefs_signed_max_and_constant_untouched():
+    from oracle.katana import AffExpr, round_coefs
+    cut = AffExpr([0, 1, 2], [-2e9, 1.0, -5.0], 7.0)
+    round_coefs(cut, 1e9)
+    assert cut.coeffs == [0.0, 1.0, -5.0] and cut.constant == 7.0       # src/model.jl:200-207
+    cut = AffExpr([0, 1], [-3e9, -1.0], 1.0)                            # signed max = -1
+    round_coefs(cut, 1e9)
+    assert cut.coeffs == [0.0, -1.0]
+
+
+def test_pdlp_mirror_solves_small_lp():
+    import scipy.sparse as sp
+    from oracle import pdlp_mirror as pm
+    A = sp.csr_matrix(np.array([[4.0, 4.0], [1.0, -1.0]]))
+    r = pm.solve_lp_halpern(A, np.array([-1.0, -1.0]), np.array([-2.0, -2.0]), np.array([2.0, 2.0]),
+                            np.array([-np.inf, -0.5]), np.array([9.0, 0.5]), params=pm.PdlpParams(eps=1e-9))
+    assert r["status"] == "Optimal" and abs(r["pobj"] + 2.25) < 1e-6
