@@ -961,6 +961,7 @@ void Engine::step(int32_t* done) {
     iter += 1;
     const double floor_p = prm.lp_tol_floor * prm.f_tol;
     double tol_p = std::min(std::max(prm.lp_tol_scale * last_maxviol, floor_p), prm.lp_tol_cap);
+    if (m_nl == 0) tol_p = floor_p;      // pure LP: one exact solve, like the reference
     double tol_g = std::min(std::max(tol_p, prm.lp_gap_floor), prm.lp_gap_cap);
     LpResult R = lp_solve(tol_p, tol_g, 0);
     lp_status = R.status;
