@@ -55,9 +55,11 @@ __global__ __launch_bounds__(kBlock) void k_hash_fill(int64_t n, double* __restr
     z[i] = 0.25 + (double)(h >> 11) * (1.0 / 9007199254740992.0);   // in [0.25, 1.25)
 }
 
+// lanes per sparse row: the power of two nearest below the average row length (a row longer
+// than G just loops), so that short-row matrices do not idle half of every wavefront
 static inline int pick_group(double avg_len) {
     int g = 4;
-    while (g < 64 && g < avg_len) g <<= 1;
+    while (g < 64 && 2 * g <= avg_len) g <<= 1;
     return g;
 }
 
@@ -174,6 +176,22 @@ struct Engine {
     struct EvRec { int kind; size_t a, b; double bytes; };
     std::vector<EvRec> ev_recs;
     size_t ev_used = 0;
+    // in-kernel wall-clock stamps (profile mode): slot s of d_pmin/d_pmax belongs to one launch
+    DBuf<unsigned long long> d_pmin, d_pmax;
+    struct TsRec { int kind; int slot; double bytes; };
+    std::vector<TsRec> ts_recs;
+    int ts_used = 0;
+    double wall_clock_hz = 1e8;
+    static constexpr int kTsSlots = 1024;
+    ProfSlot ts_get(int kind, double bytes) {
+        ProfSlot p{nullptr, nullptr};
+        if (!prm.profile || ts_used >= kTsSlots) return p;
+        p.tmin = d_pmin.p + ts_used;
+        p.tmax = d_pmax.p + ts_used;
+        ts_recs.push_back({kind, ts_used, bytes});
+        ++ts_used;
+        return p;
+    }
 
     explicit Engine(const ktn_params& p) : prm(p) {
         int ndev = 0;
@@ -190,6 +208,15 @@ struct Engine {
         chkout.resize(kChkQ * 2 + 8, stream);
         d_scal.resize(8, stream);
         d_anynf.resize(2, stream);
+        if (prm.profile) {
+            int khz = 0;
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0)
+                wall_clock_hz = 1e3 * (double)khz;
+            d_pmin.resize(kTsSlots, stream);
+            d_pmax.resize(kTsSlots, stream);
+            KTN_HIP(hipMemsetAsync(d_pmin.p, 0xFF, kTsSlots * sizeof(unsigned long long), stream));
+            KTN_HIP(hipMemsetAsync(d_pmax.p, 0, kTsSlots * sizeof(unsigned long long), stream));
+        }
     }
     ~Engine() {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -214,19 +241,36 @@ struct Engine {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ev_pool[r.a], ev_pool[r.b]) == hipSuccess) {
                 std::string k = names[r.kind];
-                stats[k + "_time_s"] += ms * 1e-3;
-                stats[k + "_launches"] += 1.0;
-                stats[k + "_bytes"] += r.bytes;
+                stats[k + "_event_time_s"] += ms * 1e-3;     // hipEvent bracket: kernel + dispatch gap
+                stats[k + "_event_launches"] += 1.0;
             }
         }
         ev_recs.clear();
         ev_used = 0;
+        if (ts_used > 0) {
+            std::vector<unsigned long long> a(ts_used), b(ts_used);
+            KTN_HIP(hipMemcpyAsync(a.data(), d_pmin.p, ts_used * 8, hipMemcpyDeviceToHost, stream));
+            KTN_HIP(hipMemcpyAsync(b.data(), d_pmax.p, ts_used * 8, hipMemcpyDeviceToHost, stream));
+            KTN_HIP(hipStreamSynchronize(stream));
+            for (auto& r : ts_recs) {
+                if (b[r.slot] >= a[r.slot] && a[r.slot] != ~0ULL) {
+                    std::string k = names[r.kind];
+                    stats[k + "_time_s"] += (double)(b[r.slot] - a[r.slot]) / wall_clock_hz;
+                    stats[k + "_launches"] += 1.0;
+                    stats[k + "_bytes"] += r.bytes;
+                }
+            }
+            KTN_HIP(hipMemsetAsync(d_pmin.p, 0xFF, ts_used * 8, stream));
+            KTN_HIP(hipMemsetAsync(d_pmax.p, 0, ts_used * 8, stream));
+            ts_recs.clear();
+            ts_used = 0;
+        }
     }
 
     // --------------------------------------------------------------- reductions ---
     double dev_dot(int64_t n, const double* a, const double* b) {
         hipLaunchKernelGGL(k_dot_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, a, b, partials.p);
-        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, stream, partials.p, kRedBlocks, chkout.p + 2 * kChkQ);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, chkout.p + 2 * kChkQ);
         double v = 0.0;
         KTN_HIP(hipMemcpyAsync(&v, chkout.p + 2 * kChkQ, sizeof(double), hipMemcpyDeviceToHost, stream));
         sync();
@@ -234,7 +278,7 @@ struct Engine {
     }
     double dev_finite_sq(int64_t n, const double* a) {
         hipLaunchKernelGGL(k_finite_sq_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, a, partials.p);
-        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, stream, partials.p, kRedBlocks, chkout.p + 2 * kChkQ);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, chkout.p + 2 * kChkQ);
         double v = 0.0;
         KTN_HIP(hipMemcpyAsync(&v, chkout.p + 2 * kChkQ, sizeof(double), hipMemcpyDeviceToHost, stream));
         sync();
@@ -277,7 +321,7 @@ struct Engine {
     void precompute_all(const double* d_x) {
         NlpDev P = nlp_view();
         SweepOut O = sweep_view();
-        LAUNCH_G(grp_sweep, k_sep_eval, m_ext, stream, P, d_allrows.p, m_ext, d_x, 0.0, 1, 0, O);
+        LAUNCH_G(grp_sweep, k_sep_eval, m_ext, stream, P, d_allrows.p, m_ext, d_x, 0.0, 1, 0, O, ProfSlot{nullptr, nullptr});
         LAUNCH_1(k_tape_eval, (int64_t)d_taperows_all.n, stream, P, d_taperows_all.p, (int64_t)d_taperows_all.n, d_x, O);
         // cut constants / maxima of tape rows from the materialised Jacobian (flags unused here)
         KTN_HIP(hipMemsetAsync(d_scal.p, 0, sizeof(double), stream));
@@ -300,7 +344,7 @@ struct Engine {
         KTN_HIP(hipMemsetAsync(d_anynf.p, 0, sizeof(int32_t), stream));
         size_t ea = 0, eb = 0;
         if (prm.profile) { ea = ev_get(); KTN_HIP(hipEventRecord(ev_pool[ea], stream)); }
-        LAUNCH_G(grp_sweep, k_sep_eval, m_nl, stream, P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O);
+        LAUNCH_G(grp_sweep, k_sep_eval, m_nl, stream, P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O, ts_get(2, sweep_bytes));
         if (prm.profile) {
             eb = ev_get(); KTN_HIP(hipEventRecord(ev_pool[eb], stream));
             ev_recs.push_back({2, ea, eb, sweep_bytes});
@@ -781,9 +825,9 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
             const double w = (double)(k + 1) / (double)(k + 2);
             size_t e0 = 0, e1 = 0, e2 = 0;
             if (prm.profile) { e0 = ev_get(); KTN_HIP(hipEventRecord(ev_pool[e0], stream)); }
-            LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+            LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho, ts_get(0, kx_bytes));
             if (prm.profile) { e1 = ev_get(); KTN_HIP(hipEventRecord(ev_pool[e1], stream)); }
-            LAUNCH_GB(grp_rows, k_pdhg_y, true, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, rho);
+            LAUNCH_GB(grp_rows, k_pdhg_y, true, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, rho, ts_get(1, ky_bytes));
             if (prm.profile) {
                 e2 = ev_get(); KTN_HIP(hipEventRecord(ev_pool[e2], stream));
                 ev_recs.push_back({0, e0, e1, kx_bytes});
@@ -793,14 +837,14 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
             continue;
         }
         // ---- check iteration: PDHG step without update, KKT + fixed-point residual
-        LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, 0.0, rho);
-        LAUNCH_GB(grp_rows, k_pdhg_y, false, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, 0.0, rho);
+        LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, 0.0, rho, ProfSlot{nullptr, nullptr});
+        LAUNCH_GB(grp_rows, k_pdhg_y, false, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, 0.0, rho, ProfSlot{nullptr, nullptr});
         hipLaunchKernelGGL(k_chk_rows, dim3(kRedBlocks), dim3(kBlock), 0, stream, m, A, xh.p, xth.p, yh.p, yth.p, y0h.p,
                            loh.p, hih.p, dr.p, partials.p);
-        hipLaunchKernelGGL(k_chk_final, dim3(1), dim3(64), 0, stream, partials.p, kRedBlocks, chkout.p);
+        hipLaunchKernelGGL(k_chk_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, chkout.p);
         hipLaunchKernelGGL(k_chk_cols, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, AT, xh.p, xth.p, x0h.p, yth.p, ch.p,
                            lh.p, uh.p, dc.p, partials.p + (size_t)kRedBlocks * kChkQ);
-        hipLaunchKernelGGL(k_chk_final, dim3(1), dim3(64), 0, stream, partials.p + (size_t)kRedBlocks * kChkQ, kRedBlocks,
+        hipLaunchKernelGGL(k_chk_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p + (size_t)kRedBlocks * kChkQ, kRedBlocks,
                            chkout.p + kChkQ);
         check_launch();
         double q[2 * kChkQ];
@@ -892,8 +936,8 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
     const double tau = eta / omega_, sigma = eta * omega_;
     for (int64_t k = 0; k < iters; ++k) {
         const double w = (double)(k + 1) / (double)(k + 2);
-        LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, 1.0);
-        LAUNCH_GB(grp_rows, k_pdhg_y, true, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, 1.0);
+        LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, 1.0, ProfSlot{nullptr, nullptr});
+        LAUNCH_GB(grp_rows, k_pdhg_y, true, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, 1.0, ProfSlot{nullptr, nullptr});
     }
     check_launch();
     KTN_HIP(hipMemcpyAsync(x_out, xh.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));

@@ -59,6 +59,15 @@ __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {
     if (v != v) v = __builtin_inf();
     if (v > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
 }
+// per-launch kernel timing (profile mode only): first workgroup start / last workgroup end on the
+// constant-rate wall clock, min/max-reduced with atomics into this launch's slot
+struct ProfSlot { unsigned long long* tmin; unsigned long long* tmax; };
+__device__ __forceinline__ void prof_begin(const ProfSlot& p) {
+    if (p.tmin && threadIdx.x == 0) atomicMin(p.tmin, (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void prof_end(const ProfSlot& p) {
+    if (p.tmax && threadIdx.x == 0) atomicMax(p.tmax, (unsigned long long)wall_clock64());
+}
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 // ------------------------------------------------------------- separable atoms ----
@@ -110,12 +119,13 @@ struct SweepOut {
 template <int G>
 __global__ __launch_bounds__(kBlock) void k_sep_eval(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
                                                      const double* __restrict__ x, double f_tol, int materialize,
-                                                     int only_flagged_nl, SweepOut O) {
+                                                     int only_flagged_nl, SweepOut O, ProfSlot prof) {
+    prof_begin(prof);
     const int64_t gid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     if (gid >= m_nl) return;
     const int32_t r = nl_rows[gid];
-    if (P.row_kind[r] != KTN_ROW_SEP) return;
+    if (P.row_kind[r] != KTN_ROW_SEP) { prof_end(prof); return; }
     const int64_t beg = P.rowptr[r], end = P.rowptr[r + 1];
     double acc_g = 0.0, acc_dot = 0.0, mx = -__builtin_inf();
     int nf = 0;
@@ -151,6 +161,7 @@ __global__ __launch_bounds__(kBlock) void k_sep_eval(NlpDev P, const int32_t* __
                 if (nf) atomicOr(O.any_nonfin, 1);
             }
         }
+        prof_end(prof);
     }
 }
 
@@ -333,7 +344,9 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_x(int64_t n, SpMat AT, const do
                                                    double* __restrict__ x, const double* __restrict__ x0,
                                                    double* __restrict__ xt, double* __restrict__ xbar,
                                                    const double* __restrict__ c, const double* __restrict__ l,
-                                                   const double* __restrict__ u, double tau, double w, double rho) {
+                                                   const double* __restrict__ u, double tau, double w, double rho,
+                                                   ProfSlot prof) {
+    prof_begin(prof);
     const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     if (j >= n) return;
@@ -347,6 +360,7 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_x(int64_t n, SpMat AT, const do
         xbar[j] = 2.0 * xtv - xv;
         if (UPDATE) x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0[j];
         else xt[j] = xtv;
+        prof_end(prof);
     }
 }
 
@@ -356,7 +370,9 @@ template <int G, bool UPDATE>
 __global__ __launch_bounds__(kBlock) void k_pdhg_y(int64_t m, SpMat A, const double* __restrict__ xbar,
                                                    double* __restrict__ y, const double* __restrict__ y0,
                                                    double* __restrict__ yt, const double* __restrict__ lo,
-                                                   const double* __restrict__ hi, double sigma, double w, double rho) {
+                                                   const double* __restrict__ hi, double sigma, double w, double rho,
+                                                   ProfSlot prof) {
+    prof_begin(prof);
     const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     if (i >= m) return;
@@ -370,6 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_y(int64_t m, SpMat A, const dou
         const double ytv = v + sigma * clampd(-v / sigma, lo[i], hi[i]);
         if (UPDATE) y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0[i];
         else yt[i] = ytv;
+        prof_end(prof);
     }
 }
 
@@ -405,15 +422,25 @@ __device__ __forceinline__ void chk_block_store(ChkAcc& a, double* partials) {
         partials[(int64_t)blockIdx.x * kChkQ + q] = v;
     }
 }
-__global__ void k_chk_final(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
-    const int q = threadIdx.x;
-    if (q >= kChkQ) return;
-    double v = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        const double p = partials[(int64_t)b * kChkQ + q];
-        v = (q < 12) ? v + p : fmax(v, p);
+// second stage of the deterministic reductions: ONE block of kRedBlocks threads, thread b owns
+// partial block b (coalesced loads), fixed-shape butterfly + LDS tree -> run-to-run identical sums
+__global__ __launch_bounds__(kRedBlocks) void k_chk_final(const double* __restrict__ partials, int nblocks,
+                                                          double* __restrict__ out) {
+    __shared__ double sh[kChkQ][kRedBlocks / 64];
+    const int b = threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < kChkQ; ++q) {
+        double v = (b < nblocks) ? partials[(int64_t)b * kChkQ + q] : 0.0;
+        v = (q < 12) ? group_sum<64>(v) : group_max<64>(v);
+        if (lane == 0) sh[q][wv] = v;
     }
-    out[q] = v;
+    __syncthreads();
+    if (threadIdx.x < kChkQ) {
+        const int q = threadIdx.x;
+        double v = sh[q][0];
+        for (int k = 1; k < kRedBlocks / 64; ++k) v = (q < 12) ? v + sh[q][k] : fmax(v, sh[q][k]);
+        out[q] = v;
+    }
 }
 
 // KKT / fixed-point quantities, row side (grid-stride, one thread per row: check
@@ -581,11 +608,17 @@ __global__ __launch_bounds__(kBlock) void k_dot_partial(int64_t n, const double*
         partials[blockIdx.x] = v;
     }
 }
-__global__ void k_sum_final(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+__global__ __launch_bounds__(kRedBlocks) void k_sum_final(const double* __restrict__ partials, int nblocks,
+                                                          double* __restrict__ out) {
+    __shared__ double sh[kRedBlocks / 64];
+    double v = ((int)threadIdx.x < nblocks) ? partials[threadIdx.x] : 0.0;
+    v = group_sum<64>(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        double v = 0.0;
-        for (int b = 0; b < nblocks; ++b) v += partials[b];
-        out[0] = v;
+        double t = 0.0;
+        for (int k = 0; k < kRedBlocks / 64; ++k) t += sh[k];
+        out[0] = t;
     }
 }
 __global__ __launch_bounds__(kBlock) void k_scale_vec(int64_t n, double* __restrict__ z, double s) {
