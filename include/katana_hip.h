@@ -222,8 +222,8 @@ int ktn_get_lp_sol(ktn_handle h, int64_t k, double* x_out, int64_t n);
 /* ---- statistics (not in the reference: measurement hooks) ----
  * names: "lp_time_s" "sep_time_s" "pdhg_iters" "lp_solves" "lp_restarts" "sweeps"
  * with params.profile = 1, per hot kernel K in {kx, ky, sweep_eval}:
- *        "K_time_s" "K_launches" "K_bytes"       device wall-clock stamps inside the kernel
- *        "K_event_time_s" "K_event_launches"     hipEvent brackets on the engine's stream */
+ *        "K_time_s" "K_launches" "K_bytes"  from the start/stop hipEvents of hipExtLaunchKernelGGL
+ *        on the engine's own stream (dispatch begin/end, as rocprofv3 --kernel-trace reports) */
 double ktn_get_stat(ktn_handle h, const char* name);
 
 /* ---- multi-GPU: row-block sharding of the NL rows + exchange of generated cuts -----

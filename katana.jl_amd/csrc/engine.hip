@@ -11,6 +11,7 @@
 // The CPU mirror of the LP algorithm used by the tests is oracle/pdlp_mirror.py
 // (solve_lp_halpern); it is test infrastructure and never linked or called from here.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -87,6 +88,35 @@ static inline int pick_group(double avg_len) {
                 case 16: hipLaunchKernelGGL((KERNEL<16, B>), dim3(ceil_div(cnt__ * 16, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
                 case 32: hipLaunchKernelGGL((KERNEL<32, B>), dim3(ceil_div(cnt__ * 32, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
                 default: hipLaunchKernelGGL((KERNEL<64, B>), dim3(ceil_div(cnt__ * 64, kBlock)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+
+// same, with the kernel's own start/stop timestamps recorded into (E0, E1)
+#define LAUNCH_G_EV(G, KERNEL, count, stream, E0, E1, ...)                                               \
+    do {                                                                                                 \
+        const int64_t cnt__ = (count);                                                                   \
+        if (cnt__ > 0) {                                                                                 \
+            switch (G) {                                                                                 \
+                case 4: hipExtLaunchKernelGGL((KERNEL<4>), dim3(ceil_div(cnt__ * 4, kBlock)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break;   \
+                case 8: hipExtLaunchKernelGGL((KERNEL<8>), dim3(ceil_div(cnt__ * 8, kBlock)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break;   \
+                case 16: hipExtLaunchKernelGGL((KERNEL<16>), dim3(ceil_div(cnt__ * 16, kBlock)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break; \
+                case 32: hipExtLaunchKernelGGL((KERNEL<32>), dim3(ceil_div(cnt__ * 32, kBlock)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break; \
+                default: hipExtLaunchKernelGGL((KERNEL<64>), dim3(ceil_div(cnt__ * 64, kBlock)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break; \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+
+#define LAUNCH_GB_EV(G, KERNEL, B, count, stream, E0, E1, ...)                                           \
+    do {                                                                                                 \
+        const int64_t cnt__ = (count);                                                                   \
+        if (cnt__ > 0) {                                                                                 \
+            switch (G) {                                                                                 \
+                case 4: hipExtLaunchKernelGGL((KERNEL<4, B>), dim3(ceil_div(cnt__ * 4, kBlock)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break;   \
+                case 8: hipExtLaunchKernelGGL((KERNEL<8, B>), dim3(ceil_div(cnt__ * 8, kBlock)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break;   \
+                case 16: hipExtLaunchKernelGGL((KERNEL<16, B>), dim3(ceil_div(cnt__ * 16, kBlock)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break; \
+                case 32: hipExtLaunchKernelGGL((KERNEL<32, B>), dim3(ceil_div(cnt__ * 32, kBlock)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break; \
+                default: hipExtLaunchKernelGGL((KERNEL<64, B>), dim3(ceil_div(cnt__ * 64, kBlock)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break; \
             }                                                                                            \
         }                                                                                                \
     } while (0)
@@ -176,22 +206,6 @@ struct Engine {
     struct EvRec { int kind; size_t a, b; double bytes; };
     std::vector<EvRec> ev_recs;
     size_t ev_used = 0;
-    // in-kernel wall-clock stamps (profile mode): slot s of d_pmin/d_pmax belongs to one launch
-    DBuf<unsigned long long> d_pmin, d_pmax;
-    struct TsRec { int kind; int slot; double bytes; };
-    std::vector<TsRec> ts_recs;
-    int ts_used = 0;
-    double wall_clock_hz = 1e8;
-    static constexpr int kTsSlots = 1024;
-    ProfSlot ts_get(int kind, double bytes) {
-        ProfSlot p{nullptr, nullptr};
-        if (!prm.profile || ts_used >= kTsSlots) return p;
-        p.tmin = d_pmin.p + ts_used;
-        p.tmax = d_pmax.p + ts_used;
-        ts_recs.push_back({kind, ts_used, bytes});
-        ++ts_used;
-        return p;
-    }
 
     explicit Engine(const ktn_params& p) : prm(p) {
         int ndev = 0;
@@ -208,15 +222,6 @@ struct Engine {
         chkout.resize(kChkQ * 2 + 8, stream);
         d_scal.resize(8, stream);
         d_anynf.resize(2, stream);
-        if (prm.profile) {
-            int khz = 0;
-            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0)
-                wall_clock_hz = 1e3 * (double)khz;
-            d_pmin.resize(kTsSlots, stream);
-            d_pmax.resize(kTsSlots, stream);
-            KTN_HIP(hipMemsetAsync(d_pmin.p, 0xFF, kTsSlots * sizeof(unsigned long long), stream));
-            KTN_HIP(hipMemsetAsync(d_pmax.p, 0, kTsSlots * sizeof(unsigned long long), stream));
-        }
     }
     ~Engine() {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -235,36 +240,21 @@ struct Engine {
         }
         return ev_used++;
     }
+    // profile mode: the timed launches go through hipExtLaunchKernelGGL, whose start/stop events
+    // carry the dispatch's own begin/end timestamps (what rocprofv3 --kernel-trace reports)
     void ev_flush() {   // stream must be synchronised
         static const char* names[3] = {"kx", "ky", "sweep_eval"};
         for (auto& r : ev_recs) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ev_pool[r.a], ev_pool[r.b]) == hipSuccess) {
                 std::string k = names[r.kind];
-                stats[k + "_event_time_s"] += ms * 1e-3;     // hipEvent bracket: kernel + dispatch gap
-                stats[k + "_event_launches"] += 1.0;
+                stats[k + "_time_s"] += ms * 1e-3;
+                stats[k + "_launches"] += 1.0;
+                stats[k + "_bytes"] += r.bytes;
             }
         }
         ev_recs.clear();
         ev_used = 0;
-        if (ts_used > 0) {
-            std::vector<unsigned long long> a(ts_used), b(ts_used);
-            KTN_HIP(hipMemcpyAsync(a.data(), d_pmin.p, ts_used * 8, hipMemcpyDeviceToHost, stream));
-            KTN_HIP(hipMemcpyAsync(b.data(), d_pmax.p, ts_used * 8, hipMemcpyDeviceToHost, stream));
-            KTN_HIP(hipStreamSynchronize(stream));
-            for (auto& r : ts_recs) {
-                if (b[r.slot] >= a[r.slot] && a[r.slot] != ~0ULL) {
-                    std::string k = names[r.kind];
-                    stats[k + "_time_s"] += (double)(b[r.slot] - a[r.slot]) / wall_clock_hz;
-                    stats[k + "_launches"] += 1.0;
-                    stats[k + "_bytes"] += r.bytes;
-                }
-            }
-            KTN_HIP(hipMemsetAsync(d_pmin.p, 0xFF, ts_used * 8, stream));
-            KTN_HIP(hipMemsetAsync(d_pmax.p, 0, ts_used * 8, stream));
-            ts_recs.clear();
-            ts_used = 0;
-        }
     }
 
     // --------------------------------------------------------------- reductions ---
@@ -321,7 +311,7 @@ struct Engine {
     void precompute_all(const double* d_x) {
         NlpDev P = nlp_view();
         SweepOut O = sweep_view();
-        LAUNCH_G(grp_sweep, k_sep_eval, m_ext, stream, P, d_allrows.p, m_ext, d_x, 0.0, 1, 0, O, ProfSlot{nullptr, nullptr});
+        LAUNCH_G(grp_sweep, k_sep_eval, m_ext, stream, P, d_allrows.p, m_ext, d_x, 0.0, 1, 0, O);
         LAUNCH_1(k_tape_eval, (int64_t)d_taperows_all.n, stream, P, d_taperows_all.p, (int64_t)d_taperows_all.n, d_x, O);
         // cut constants / maxima of tape rows from the materialised Jacobian (flags unused here)
         KTN_HIP(hipMemsetAsync(d_scal.p, 0, sizeof(double), stream));
@@ -342,12 +332,12 @@ struct Engine {
         SweepOut O = sweep_view();
         KTN_HIP(hipMemsetAsync(d_scal.p, 0, sizeof(double), stream));
         KTN_HIP(hipMemsetAsync(d_anynf.p, 0, sizeof(int32_t), stream));
-        size_t ea = 0, eb = 0;
-        if (prm.profile) { ea = ev_get(); KTN_HIP(hipEventRecord(ev_pool[ea], stream)); }
-        LAUNCH_G(grp_sweep, k_sep_eval, m_nl, stream, P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O, ts_get(2, sweep_bytes));
         if (prm.profile) {
-            eb = ev_get(); KTN_HIP(hipEventRecord(ev_pool[eb], stream));
+            const size_t ea = ev_get(), eb = ev_get();
+            LAUNCH_G_EV(grp_sweep, k_sep_eval, m_nl, stream, ev_pool[ea], ev_pool[eb], P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O);
             ev_recs.push_back({2, ea, eb, sweep_bytes});
+        } else {
+            LAUNCH_G(grp_sweep, k_sep_eval, m_nl, stream, P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O);
         }
         if (n_tape_nl > 0) {
             LAUNCH_1(k_tape_eval, n_tape_nl, stream, P, d_taperows_nl.p, n_tape_nl, d_x, O);
@@ -823,22 +813,24 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
         const bool check = (it % chk == 0) || k == 0;
         if (!check) {
             const double w = (double)(k + 1) / (double)(k + 2);
-            size_t e0 = 0, e1 = 0, e2 = 0;
-            if (prm.profile) { e0 = ev_get(); KTN_HIP(hipEventRecord(ev_pool[e0], stream)); }
-            LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho, ts_get(0, kx_bytes));
-            if (prm.profile) { e1 = ev_get(); KTN_HIP(hipEventRecord(ev_pool[e1], stream)); }
-            LAUNCH_GB(grp_rows, k_pdhg_y, true, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, rho, ts_get(1, ky_bytes));
             if (prm.profile) {
-                e2 = ev_get(); KTN_HIP(hipEventRecord(ev_pool[e2], stream));
+                const size_t e0 = ev_get(), e1 = ev_get(), e2 = ev_get(), e3 = ev_get();
+                LAUNCH_GB_EV(grp_cols, k_pdhg_x, true, n, stream, ev_pool[e0], ev_pool[e1], n, AT, yh.p, xh.p, x0h.p, xth.p,
+                             xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+                LAUNCH_GB_EV(grp_rows, k_pdhg_y, true, m, stream, ev_pool[e2], ev_pool[e3], m, A, xbar.p, yh.p, y0h.p, yth.p,
+                             loh.p, hih.p, sigma, w, rho);
                 ev_recs.push_back({0, e0, e1, kx_bytes});
-                ev_recs.push_back({1, e1, e2, ky_bytes});
+                if (m > 0) ev_recs.push_back({1, e2, e3, ky_bytes});
+            } else {
+                LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+                LAUNCH_GB(grp_rows, k_pdhg_y, true, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, rho);
             }
             ++k; ++it;
             continue;
         }
         // ---- check iteration: PDHG step without update, KKT + fixed-point residual
-        LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, 0.0, rho, ProfSlot{nullptr, nullptr});
-        LAUNCH_GB(grp_rows, k_pdhg_y, false, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, 0.0, rho, ProfSlot{nullptr, nullptr});
+        LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, 0.0, rho);
+        LAUNCH_GB(grp_rows, k_pdhg_y, false, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, 0.0, rho);
         hipLaunchKernelGGL(k_chk_rows, dim3(kRedBlocks), dim3(kBlock), 0, stream, m, A, xh.p, xth.p, yh.p, yth.p, y0h.p,
                            loh.p, hih.p, dr.p, partials.p);
         hipLaunchKernelGGL(k_chk_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, chkout.p);
@@ -936,8 +928,8 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
     const double tau = eta / omega_, sigma = eta * omega_;
     for (int64_t k = 0; k < iters; ++k) {
         const double w = (double)(k + 1) / (double)(k + 2);
-        LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, 1.0, ProfSlot{nullptr, nullptr});
-        LAUNCH_GB(grp_rows, k_pdhg_y, true, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, 1.0, ProfSlot{nullptr, nullptr});
+        LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, 1.0);
+        LAUNCH_GB(grp_rows, k_pdhg_y, true, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, 1.0);
     }
     check_launch();
     KTN_HIP(hipMemcpyAsync(x_out, xh.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));

@@ -59,15 +59,6 @@ __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {
     if (v != v) v = __builtin_inf();
     if (v > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
 }
-// per-launch kernel timing (profile mode only): first workgroup start / last workgroup end on the
-// constant-rate wall clock, min/max-reduced with atomics into this launch's slot
-struct ProfSlot { unsigned long long* tmin; unsigned long long* tmax; };
-__device__ __forceinline__ void prof_begin(const ProfSlot& p) {
-    if (p.tmin && threadIdx.x == 0) atomicMin(p.tmin, (unsigned long long)wall_clock64());
-}
-__device__ __forceinline__ void prof_end(const ProfSlot& p) {
-    if (p.tmax && threadIdx.x == 0) atomicMax(p.tmax, (unsigned long long)wall_clock64());
-}
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 // ------------------------------------------------------------- separable atoms ----
@@ -119,13 +110,12 @@ struct SweepOut {
 template <int G>
 __global__ __launch_bounds__(kBlock) void k_sep_eval(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
                                                      const double* __restrict__ x, double f_tol, int materialize,
-                                                     int only_flagged_nl, SweepOut O, ProfSlot prof) {
-    prof_begin(prof);
+                                                     int only_flagged_nl, SweepOut O) {
     const int64_t gid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     if (gid >= m_nl) return;
     const int32_t r = nl_rows[gid];
-    if (P.row_kind[r] != KTN_ROW_SEP) { prof_end(prof); return; }
+    if (P.row_kind[r] != KTN_ROW_SEP) return;
     const int64_t beg = P.rowptr[r], end = P.rowptr[r + 1];
     double acc_g = 0.0, acc_dot = 0.0, mx = -__builtin_inf();
     int nf = 0;
@@ -161,7 +151,6 @@ __global__ __launch_bounds__(kBlock) void k_sep_eval(NlpDev P, const int32_t* __
                 if (nf) atomicOr(O.any_nonfin, 1);
             }
         }
-        prof_end(prof);
     }
 }
 
@@ -344,9 +333,7 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_x(int64_t n, SpMat AT, const do
                                                    double* __restrict__ x, const double* __restrict__ x0,
                                                    double* __restrict__ xt, double* __restrict__ xbar,
                                                    const double* __restrict__ c, const double* __restrict__ l,
-                                                   const double* __restrict__ u, double tau, double w, double rho,
-                                                   ProfSlot prof) {
-    prof_begin(prof);
+                                                   const double* __restrict__ u, double tau, double w, double rho) {
     const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     if (j >= n) return;
@@ -360,7 +347,6 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_x(int64_t n, SpMat AT, const do
         xbar[j] = 2.0 * xtv - xv;
         if (UPDATE) x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0[j];
         else xt[j] = xtv;
-        prof_end(prof);
     }
 }
 
@@ -370,9 +356,7 @@ template <int G, bool UPDATE>
 __global__ __launch_bounds__(kBlock) void k_pdhg_y(int64_t m, SpMat A, const double* __restrict__ xbar,
                                                    double* __restrict__ y, const double* __restrict__ y0,
                                                    double* __restrict__ yt, const double* __restrict__ lo,
-                                                   const double* __restrict__ hi, double sigma, double w, double rho,
-                                                   ProfSlot prof) {
-    prof_begin(prof);
+                                                   const double* __restrict__ hi, double sigma, double w, double rho) {
     const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     if (i >= m) return;
@@ -386,7 +370,6 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_y(int64_t m, SpMat A, const dou
         const double ytv = v + sigma * clampd(-v / sigma, lo[i], hi[i]);
         if (UPDATE) y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0[i];
         else yt[i] = ytv;
-        prof_end(prof);
     }
 }
 
