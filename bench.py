@@ -109,12 +109,19 @@ def main():
         assert world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Katana HIP engine has no CPU path")
+    # KTN_BENCH_BACKEND=gloo rehearses the N > 1 path on a one-GPU box (all ranks share cuda:0)
+    backend = os.environ.get("KTN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     import katana_jl_amd as ktn
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     inst = ktn.instances.make_config(args.workload, seed=args.seed)
     if world > 1:
@@ -140,7 +147,7 @@ def main():
     elapsed = time.perf_counter() - t0
     pdhg_timed = model.stat("pdhg_iters") - p0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -33,7 +33,6 @@ extern "C" {
 #define KTN_E_NOMEM      -4
 #define KTN_E_UNSUPPORTED -5  /* e.g. unknown tape opcode ("Unsupported feature",
                                  src/nlpeval.jl:28)                                  */
-#define KTN_E_EXCHANGE   -6   /* the multi-GPU exchange callback failed              */
 
 /* ---- status vocabulary: MathProgBase.status(m) symbols ------------------------
  * :None src/model.jl:44, :Optimal, :Unbounded :246, LP pass-through e.g. :Infeasible
@@ -226,17 +225,23 @@ int ktn_get_lp_sol(ktn_handle h, int64_t k, double* x_out, int64_t n);
  *        on the engine's own stream (dispatch begin/end, as rocprofv3 --kernel-trace reports) */
 double ktn_get_stat(ktn_handle h, const char* name);
 
-/* ---- multi-GPU: row-block sharding of the NL rows + exchange of generated cuts -----
- * (no reference counterpart).  rank r owns NL rows
- * [r*m_nl/world, (r+1)*m_nl/world).  After every sweep the library packs the local cuts
- * into `send` and calls `xchg`; the callback (RCCL all-gather through torch.distributed
- * in the Python host) must fill `recv` with every rank's block in rank order and
- * `recv_counts[2*r] = rows, [2*r+1] = nnz` of rank r.  Buffers are device pointers. */
-typedef int (*ktn_exchange_fn)(void* user, const void* send, int64_t send_bytes,
-                               void* recv, int64_t recv_bytes_per_rank,
-                               int64_t* recv_counts, const int64_t* my_counts);
-int ktn_set_shard(ktn_handle h, int32_t rank, int32_t world);
-int ktn_set_exchange(ktn_handle h, ktn_exchange_fn fn, void* user);
+/* ---- multi-GPU building blocks (no reference counterpart) -----
+ * The NL rows shard by contiguous blocks: every rank loads the linear rows plus ITS block
+ * of NL rows, sweeps it, and the generated cuts are exchanged (RCCL all-gather through
+ * torch.distributed in katana.jl_amd/distributed.py) and appended in rank order so that
+ * every rank holds the identical LP.  These calls are what that host loop is made of:
+ *   ktn_sweep_lp_point   : the loop body of src/model.jl:268-283 at the current LP solution
+ *   ktn_lp_get_rows_from : export the rows appended since `first_row` (rowptr rebased to 0)
+ *   ktn_lp_truncate      : drop the rows >= nrows again (own cuts are re-appended in rank order)
+ *   ktn_lp_append_rows   : append a CSR block of rows (rowptr 0-based), duals start at 0
+ * Use lp_dual_inherit = 0 with truncate/append (row indices of earlier cuts change). */
+int ktn_sweep_lp_point(ktn_handle h, double f_tol, int64_t* nviol, double* maxviol);
+int64_t ktn_lp_nnz_from(ktn_handle h, int64_t first_row);
+int ktn_lp_get_rows_from(ktn_handle h, int64_t first_row, int64_t* rowptr, int32_t* col, double* val,
+                         double* lo, double* hi);
+int ktn_lp_truncate(ktn_handle h, int64_t nrows);
+int ktn_lp_append_rows(ktn_handle h, int64_t nrows, const int64_t* rowptr, const int32_t* col,
+                       const double* val, const double* lo, const double* hi);
 
 #ifdef __cplusplus
 }

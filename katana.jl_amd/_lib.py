@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libkatana_hip.so")
 
 KTN_OK = 0
-E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_EXCHANGE = -1, -2, -3, -4, -5, -6
+E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5
 STATUS_NONE, STATUS_OPTIMAL, STATUS_UNBOUNDED, STATUS_INFEASIBLE, STATUS_USERLIMIT, STATUS_ERROR = range(6)
 MIN, MAX = 0, 1
 ROW_SEP, ROW_TAPE = 0, 1
@@ -34,8 +34,6 @@ class KtnNlpDesc(C.Structure):
                 ("obj_col", P(c_i32)), ("obj_atom_kind", P(c_u8)), ("obj_p0", P(c_f64)), ("obj_p1", P(c_f64)),
                 ("obj_const", c_f64), ("obj_tape_len", c_i64), ("obj_tape_op", P(c_i32)), ("obj_tape_arg", P(c_f64))]
 
-
-EXCHANGE_FN = C.CFUNCTYPE(c_i32, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, c_i64, P(c_i64), P(c_i64))
 
 # name -> (restype, argtypes); every function declared in include/katana_hip.h
 PROTOTYPES = {
@@ -78,8 +76,11 @@ PROTOTYPES = {
     "ktn_num_lp_sols": (c_i64, [C.c_void_p]),
     "ktn_get_lp_sol": (c_i32, [C.c_void_p, c_i64, P(c_f64), c_i64]),
     "ktn_get_stat": (c_f64, [C.c_void_p, C.c_char_p]),
-    "ktn_set_shard": (c_i32, [C.c_void_p, c_i32, c_i32]),
-    "ktn_set_exchange": (c_i32, [C.c_void_p, EXCHANGE_FN, C.c_void_p]),
+    "ktn_sweep_lp_point": (c_i32, [C.c_void_p, c_f64, P(c_i64), P(c_f64)]),
+    "ktn_lp_nnz_from": (c_i64, [C.c_void_p, c_i64]),
+    "ktn_lp_get_rows_from": (c_i32, [C.c_void_p, c_i64, P(c_i64), P(c_i32), P(c_f64), P(c_f64), P(c_f64)]),
+    "ktn_lp_truncate": (c_i32, [C.c_void_p, c_i64]),
+    "ktn_lp_append_rows": (c_i32, [C.c_void_p, c_i64, P(c_i64), P(c_i32), P(c_f64), P(c_f64), P(c_f64)]),
 }
 
 _lib = None

@@ -1290,18 +1290,96 @@ double ktn_get_stat(ktn_handle h, const char* name) {
     return it == h->eng->stats.end() ? 0.0 : it->second;
 }
 
-int ktn_set_shard(ktn_handle h, int32_t rank, int32_t world) {
-    (void)rank;
-    if (!h || !h->eng) return KTN_E_INVALID;
-    if (world == 1) return KTN_OK;
-    h->err = "in-library sharding is not implemented in this round: shard in the host (katana.jl_amd/distributed.py)";
-    return KTN_E_UNSUPPORTED;
+// ---- multi-GPU building blocks
+int ktn_sweep_lp_point(ktn_handle h, double f_tol, int64_t* nviol, double* maxviol) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded, "no problem loaded");
+        int64_t nv = 0; double mv = 0.0; bool nf = false;
+        e->sweep(e->lp_x.p, f_tol, &nv, &mv, &nf);
+        if (nviol) *nviol = nv;
+        if (maxviol) *maxviol = mv;
+        if (nf) e->status = KTN_STATUS_ERROR;
+        return KTN_OK;
+    })
 }
-int ktn_set_exchange(ktn_handle h, ktn_exchange_fn fn, void* user) {
-    (void)fn; (void)user;
-    if (!h || !h->eng) return KTN_E_INVALID;
-    h->err = "in-library exchange is not implemented in this round: exchange in the host (katana.jl_amd/distributed.py)";
-    return KTN_E_UNSUPPORTED;
+int64_t ktn_lp_nnz_from(ktn_handle h, int64_t first_row) {
+    if (!h || !h->eng || !h->eng->loaded) return -1;
+    Engine* e = h->eng;
+    if (first_row < 0 || first_row > e->M) return -1;
+    int64_t base = 0;
+    if (hipMemcpyAsync(&base, e->lp_rowptr.p + first_row, 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
+    return e->NNZ - base;
+}
+int ktn_lp_get_rows_from(ktn_handle h, int64_t first_row, int64_t* rowptr, int32_t* col, double* val, double* lo,
+                         double* hi) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && first_row >= 0 && first_row <= e->M, "bad first_row");
+        const int64_t nr = e->M - first_row;
+        KTN_HIP(hipMemcpyAsync(rowptr, e->lp_rowptr.p + first_row, (size_t)(nr + 1) * 8, hipMemcpyDeviceToHost, e->stream));
+        e->sync();
+        const int64_t base = rowptr[0], nz = e->NNZ - base;
+        for (int64_t i = 0; i <= nr; ++i) rowptr[i] -= base;
+        if (nz > 0) {
+            KTN_HIP(hipMemcpyAsync(col, e->lp_col.p + base, (size_t)nz * 4, hipMemcpyDeviceToHost, e->stream));
+            KTN_HIP(hipMemcpyAsync(val, e->lp_val.p + base, (size_t)nz * 8, hipMemcpyDeviceToHost, e->stream));
+        }
+        if (nr > 0) {
+            KTN_HIP(hipMemcpyAsync(lo, e->lp_lo.p + first_row, (size_t)nr * 8, hipMemcpyDeviceToHost, e->stream));
+            KTN_HIP(hipMemcpyAsync(hi, e->lp_hi.p + first_row, (size_t)nr * 8, hipMemcpyDeviceToHost, e->stream));
+        }
+        e->sync();
+        return KTN_OK;
+    })
+}
+int ktn_lp_truncate(ktn_handle h, int64_t nrows) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && nrows >= e->M_base && nrows <= e->M, "truncate: nrows outside [base rows, current rows]");
+        int64_t base = 0;
+        KTN_HIP(hipMemcpyAsync(&base, e->lp_rowptr.p + nrows, 8, hipMemcpyDeviceToHost, e->stream));
+        e->sync();
+        e->numcuts -= (e->M - nrows);
+        e->M = nrows; e->NNZ = base;
+        e->lp_rowptr.n = (size_t)nrows + 1; e->lp_col.n = e->lp_val.n = (size_t)base;
+        e->lp_lo.n = e->lp_hi.n = e->lp_y.n = (size_t)nrows;
+        e->lp_dirty = true;
+        return KTN_OK;
+    })
+}
+int ktn_lp_append_rows(ktn_handle h, int64_t nrows, const int64_t* rowptr, const int32_t* col, const double* val,
+                       const double* lo, const double* hi) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && nrows >= 0, "append: bad arguments");
+        if (nrows == 0) return KTN_OK;
+        const int64_t nz = rowptr[nrows] - rowptr[0];
+        std::vector<int64_t> rp((size_t)nrows);
+        for (int64_t i = 0; i < nrows; ++i) {
+            KTN_REQUIRE(rowptr[i + 1] >= rowptr[i], "append: rowptr not monotone");
+            rp[(size_t)i] = rowptr[i + 1] - rowptr[0] + e->NNZ;
+        }
+        for (int64_t k = 0; k < nz; ++k) KTN_REQUIRE(col[rowptr[0] + k] >= 0 && col[rowptr[0] + k] < e->n_lp, "append: column out of range");
+        hipStream_t s = e->stream;
+        e->lp_rowptr.resize((size_t)(e->M + nrows + 1), s);
+        e->lp_lo.resize((size_t)(e->M + nrows), s); e->lp_hi.resize((size_t)(e->M + nrows), s);
+        e->lp_y.resize((size_t)(e->M + nrows), s);
+        e->lp_col.resize((size_t)(e->NNZ + nz), s); e->lp_val.resize((size_t)(e->NNZ + nz), s);
+        KTN_HIP(hipMemcpyAsync(e->lp_rowptr.p + e->M + 1, rp.data(), (size_t)nrows * 8, hipMemcpyHostToDevice, s));
+        KTN_HIP(hipMemcpyAsync(e->lp_lo.p + e->M, lo, (size_t)nrows * 8, hipMemcpyHostToDevice, s));
+        KTN_HIP(hipMemcpyAsync(e->lp_hi.p + e->M, hi, (size_t)nrows * 8, hipMemcpyHostToDevice, s));
+        KTN_HIP(hipMemsetAsync(e->lp_y.p + e->M, 0, (size_t)nrows * 8, s));
+        if (nz > 0) {
+            KTN_HIP(hipMemcpyAsync(e->lp_col.p + e->NNZ, col + rowptr[0], (size_t)nz * 4, hipMemcpyHostToDevice, s));
+            KTN_HIP(hipMemcpyAsync(e->lp_val.p + e->NNZ, val + rowptr[0], (size_t)nz * 8, hipMemcpyHostToDevice, s));
+        }
+        e->sync();
+        e->M += nrows; e->NNZ += nz; e->numcuts += nrows;
+        e->lp_dirty = true;
+        return KTN_OK;
+    })
 }
 
 }  // extern "C"

@@ -1,0 +1,182 @@
+"""Multi-GPU ECP: NL rows sharded by contiguous blocks, replicated LP, one exchange of the
+generated cuts per ECP iteration (no counterpart in the serial reference).
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on
+CPU for the tests).  Given x*, every nonlinear row is evaluated and cut independently
+(`for i in m.nlconstr_ixs`, src/model.jl:272-283), so rank r sweeps only its block of rows.
+The cuts are then all-gathered -- two collectives per iteration: the (rows, nnz) counts, then
+the cut blocks padded to the largest -- and appended on every rank in RANK ORDER, so that all
+ranks hold the identical LP and the deterministic GPU LP gives them the identical x*.
+
+The loop below is the host-level statement of Engine::step (csrc/engine.hip) with the exchange
+between sweep and append; it drives the same kernels through the C ABI.
+"""
+import numpy as np
+
+from .instances import SeparableInstance
+from .nlp import SeparableNLP
+from .solver import NonlinearModel
+
+
+def shard_bounds(m_nl, rank, world):
+    """contiguous block [lo, hi) of the NL rows owned by `rank`"""
+    return (m_nl * rank) // world, (m_nl * (rank + 1)) // world
+
+
+def shard_instance(inst, rank, world):
+    """all linear rows + this rank's block of NL rows (same variables, same objective)"""
+    lo, hi = shard_bounds(inst.m_nl, rank, world)
+    rp = np.asarray(inst.rowptr)
+    ml = inst.m_lin
+    a, b = rp[ml + lo], rp[ml + hi]
+    keep = np.concatenate([np.arange(0, rp[ml]), np.arange(a, b)])
+    rows = np.concatenate([np.arange(0, ml), np.arange(ml + lo, ml + hi)])
+    new_rp = np.concatenate([rp[:ml + 1], rp[ml] + (rp[ml + lo + 1:ml + hi + 1] - a)])
+    return SeparableInstance(
+        n=inst.n, l_var=inst.l_var, u_var=inst.u_var, sense=inst.sense, rowptr=new_rp.astype(np.int64),
+        col=np.asarray(inst.col)[keep], kind=np.asarray(inst.kind)[keep], p0=np.asarray(inst.p0)[keep],
+        p1=np.asarray(inst.p1)[keep], rconst=np.asarray(inst.rconst)[rows], l_constr=np.asarray(inst.l_constr)[rows],
+        u_constr=np.asarray(inst.u_constr)[rows], obj_col=inst.obj_col, obj_kind=inst.obj_kind, obj_p0=inst.obj_p0,
+        obj_p1=inst.obj_p1, obj_const=inst.obj_const, xhat=inst.xhat, opt_obj=inst.opt_obj, m_lin=ml, m_nl=hi - lo,
+        meta=dict(inst.meta, shard=(rank, world)))
+
+
+def pack_block(rowptr, col, val, lo, hi):
+    """one f64 buffer: [rowptr[1:], col, val, lo, hi]  (integers are exact in f64)"""
+    return np.concatenate([np.asarray(rowptr[1:], dtype=np.float64), np.asarray(col, dtype=np.float64),
+                           np.asarray(val, dtype=np.float64), np.asarray(lo, dtype=np.float64),
+                           np.asarray(hi, dtype=np.float64)])
+
+
+def unpack_block(buf, nrows, nnz):
+    o = 0
+    rp = np.concatenate([[0], buf[o:o + nrows].astype(np.int64)]); o += nrows
+    col = buf[o:o + nnz].astype(np.int32); o += nnz
+    val = buf[o:o + nnz].copy(); o += nnz
+    lo = buf[o:o + nrows].copy(); o += nrows
+    hi = buf[o:o + nrows].copy()
+    return rp, col, val, lo, hi
+
+
+def exchange_cuts(dist, block, device="cpu"):
+    """All-gather one cut block per rank.  `block` = (rowptr, col, val, lo, hi) of the local cuts.
+    Returns the list of blocks in rank order.  With dist=None (single process) it is the identity."""
+    import torch
+    rowptr, col, val, lo, hi = block
+    nrows, nnz = len(lo), len(col)
+    if dist is None or dist.get_world_size() == 1:
+        return [block]
+    world = dist.get_world_size()
+    counts = torch.tensor([nrows, nnz], dtype=torch.int64, device=device)
+    all_counts = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(all_counts, counts)                       # collective 1: sizes
+    all_counts = [tuple(int(v) for v in c.cpu()) for c in all_counts]
+    width = max(3 * r + 2 * z for r, z in all_counts)
+    if width == 0:
+        return [(np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0), np.zeros(0))
+                for _ in range(world)]
+    send = torch.zeros(width, dtype=torch.float64, device=device)
+    payload = pack_block(rowptr, col, val, lo, hi)
+    send[:len(payload)] = torch.from_numpy(payload).to(device)
+    recv = [torch.empty(width, dtype=torch.float64, device=device) for _ in range(world)]
+    dist.all_gather(recv, send)                               # collective 2: padded cut blocks
+    return [unpack_block(recv[r].cpu().numpy(), *all_counts[r]) for r in range(world)]
+
+
+class ShardedKatanaModel:
+    """KatanaNonlinearModel over `world` GPUs: same getters, same stepping interface."""
+
+    def __init__(self, solver, inst, rank, world, dist=None, exchange_device=None):
+        self.rank, self.world, self.dist = rank, world, dist
+        solver.gpu_options = dict(solver.gpu_options, lp_dual_inherit=0)
+        self.p = dict(solver.model_params)
+        self.inst = inst
+        self.local = shard_instance(inst, rank, world)
+        self.m = NonlinearModel(solver)
+        self.m.loadproblem(self.local.n, self.local.num_constr, self.local.l_var, self.local.u_var,
+                           self.local.l_constr, self.local.u_constr, self.local.sense, SeparableNLP(self.local))
+        prm = self.m.params
+        self.tol = dict(scale=prm.lp_tol_scale, floor=prm.lp_tol_floor, cap=prm.lp_tol_cap, gfloor=prm.lp_gap_floor,
+                        gcap=prm.lp_gap_cap)
+        if exchange_device is None:
+            exchange_device = "cpu" if (dist is None or dist.get_backend() == "gloo") else "cuda"
+        self.exchange_device = exchange_device
+        self.num_var = self.m.num_var
+        self._reset_state()
+
+    def _reset_state(self):
+        self.iter, self.allsat, self._status, self.last_maxviol = 0, False, "None", 1e300
+        self.exchanged_rows = 0
+
+    def reset(self):
+        self.m.reset()
+        self._reset_state()
+
+    def optimize_begin(self):
+        self.m.optimize_begin()          # box-bounded shards: no presolve work, starts the solve timer
+
+    def ecp_step(self):
+        """one pass of src/model.jl:258-308 across all ranks; returns True when the loop ends"""
+        if self.allsat or self.iter >= self.p["iter_cap"] or self._status in ("Error", "Unbounded"):
+            return True
+        self.iter += 1
+        f_tol = self.p["f_tol"]
+        floor_p = self.tol["floor"] * f_tol
+        tol_p = min(max(self.tol["scale"] * self.last_maxviol, floor_p), self.tol["cap"])
+        tol_g = min(max(tol_p, self.tol["gfloor"]), self.tol["gcap"])
+        lp_status, _ = self.m.lp_solve(tol_p, tol_g)
+        if lp_status != "Optimal":
+            self._status = lp_status
+            return True
+        m0 = self.m.lp_num_rows()
+        nv_local, mv_local = self.m.sweep_lp_point(f_tol)
+        err_local = self.m.status() == "Error"
+        block = self.m.lp_rows_from(m0)
+        self.m.lp_truncate(m0)
+        blocks = exchange_cuts(self.dist, block, self.exchange_device)
+        nviol = 0
+        for rp, col, val, lo, hi in blocks:                      # rank order => identical LP everywhere
+            self.m.lp_append_rows(rp, col, val, lo, hi)
+            nviol += len(lo)
+        self.exchanged_rows += nviol
+        maxviol, any_err = self._allreduce_max(mv_local, 1.0 if err_local else 0.0)
+        if any_err > 0:
+            self._status = "Error"
+            return True
+        self.last_maxviol = maxviol
+        if nviol == 0 and tol_p > floor_p * (1 + 1e-12):
+            self.last_maxviol = 0.0                                # satisfied at a loosely solved LP: tighten first
+        else:
+            self.allsat = nviol == 0
+        return self.allsat or self.iter >= self.p["iter_cap"]
+
+    def _allreduce_max(self, a, b):
+        if self.dist is None or self.world == 1:
+            return a, b
+        import torch
+        t = torch.tensor([a, b], dtype=torch.float64, device=self.exchange_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        t = t.cpu()
+        return float(t[0]), float(t[1])
+
+    def optimize_end(self):
+        self.m.optimize_end()
+        if self._status in ("Error", "Unbounded", "UserLimit", "Infeasible"):
+            return self._status
+        self._status = "UserLimit" if self.iter >= self.p["iter_cap"] else "Optimal"
+        return self._status
+
+    def optimize(self):
+        self.optimize_begin()
+        while not self.ecp_step():
+            pass
+        return self.optimize_end()
+
+    # getters of the plugin surface
+    def status(self): return self._status
+    def getobjval(self): return self.m.getobjval()
+    def getsolution(self): return self.m.getsolution()
+    def getsolvetime(self): return self.m.getsolvetime()
+    def numiters(self): return self.iter
+    def numcuts(self): return self.m.numcuts()
+    def stat(self, name): return self.m.stat(name)

@@ -166,6 +166,39 @@ class KatanaNonlinearModel:
         L.check(self._h, self._lib.ktn_lp_solve(self._h, row_tol, gap_tol, C.byref(st), C.byref(it)))
         return STATUS_SYMBOLS[st.value], int(it.value)
 
+    # ---- multi-GPU building blocks (include/katana_hip.h "multi-GPU building blocks") ------
+    def lp_num_rows(self):
+        return int(self._lib.ktn_lp_num_rows(self._h))
+
+    def sweep_lp_point(self, f_tol):
+        nv, mv = C.c_int64(0), C.c_double(0.0)
+        L.check(self._h, self._lib.ktn_sweep_lp_point(self._h, f_tol, C.byref(nv), C.byref(mv)))
+        return int(nv.value), float(mv.value)
+
+    def lp_rows_from(self, first_row):
+        nr = self.lp_num_rows() - first_row
+        nz = int(self._lib.ktn_lp_nnz_from(self._h, first_row))
+        rowptr, col = np.zeros(nr + 1, dtype=np.int64), np.zeros(max(nz, 1), dtype=np.int32)
+        val, lo, hi = np.zeros(max(nz, 1)), np.zeros(max(nr, 1)), np.zeros(max(nr, 1))
+        L.check(self._h, self._lib.ktn_lp_get_rows_from(self._h, first_row, _p(rowptr, C.c_int64), _p(col, C.c_int32),
+                                                        _p(val), _p(lo), _p(hi)))
+        return rowptr, col[:nz], val[:nz], lo[:nr], hi[:nr]
+
+    def lp_truncate(self, nrows):
+        L.check(self._h, self._lib.ktn_lp_truncate(self._h, nrows))
+
+    def lp_append_rows(self, rowptr, col, val, lo, hi):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        nr = len(rowptr) - 1
+        if nr <= 0:
+            return
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val, lo, hi = _f64(val), _f64(lo), _f64(hi)
+        colp = col if len(col) else np.zeros(1, dtype=np.int32)
+        valp = val if len(val) else np.zeros(1)
+        L.check(self._h, self._lib.ktn_lp_append_rows(self._h, nr, _p(rowptr, C.c_int64), _p(colp, C.c_int32), _p(valp),
+                                                      _p(lo), _p(hi)))
+
     def lp_pdhg_raw(self, x0, y0, eta, omega, iters):
         x0, y0 = _f64(x0), _f64(y0)
         m = int(self._lib.ktn_lp_num_rows(self._h))

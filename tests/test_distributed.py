@@ -1,0 +1,158 @@
+"""N > 1 path: row-block sharding + exchange of cuts.
+
+CPU tier (gloo, world_size 2): the host logic that every rank runs -- shard boundaries, block
+packing, the two all-gathers, rank-ordered merge -- with the oracle's sweep standing in for the
+kernel (test-side only) so that the merged cut set can be compared with a single-process sweep.
+GPU tier: the same two-process run on real kernels (gloo exchange, both ranks on cuda:0) against
+the single-GPU solve."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_cut_block(inst, x, f_tol=1e-6):
+    """cuts of all violated NL rows of `inst` at x, as (rowptr, col, val, lo, hi) -- oracle arithmetic"""
+    from helpers import oracle_evaluator
+    from oracle.katana import KatanaFirstOrderSeparator, linear_oa_cut, round_coefs
+    sep = KatanaFirstOrderSeparator()
+    sep.initialize(None, inst.n, inst.num_constr, oracle_evaluator(inst))
+    sep.precompute(x)
+    rp, col, val, lo, hi = [0], [], [], [], []
+    for i in range(inst.m_lin, inst.num_constr):
+        if not sep.isconstrsat(i, inst.l_constr[i], inst.u_constr[i], f_tol):
+            cut = linear_oa_cut(sep, x, None, i)
+            round_coefs(cut, 1e9)
+            col += list(cut.vars); val += list(cut.coeffs); rp.append(len(col))
+            lo.append(inst.l_constr[i] - cut.constant); hi.append(inst.u_constr[i] - cut.constant)
+    return (np.array(rp, dtype=np.int64), np.array(col, dtype=np.int32), np.array(val), np.array(lo), np.array(hi))
+
+
+def _worker_exchange(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import katana_jl_amd as ktn
+    from katana_jl_amd.distributed import exchange_cuts, shard_instance
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    inst = ktn.instances.make_instance(n=800, m_nl=81, k=12, family="explog", seed=13)
+    x = np.clip(inst.xhat + 0.9, inst.l_var, inst.u_var)
+    local = shard_instance(inst, rank, world)
+    blocks = exchange_cuts(dist, _oracle_cut_block(local, x), "cpu")
+    # a second, empty round (late ECP iterations exchange nothing)
+    empty = (np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0), np.zeros(0))
+    blocks2 = exchange_cuts(dist, empty, "cpu")
+    out[rank] = (blocks, [len(b[3]) for b in blocks2])
+    dist.destroy_process_group()
+
+
+def test_exchange_merges_shard_cuts_into_the_single_process_cut_set():
+    import katana_jl_amd as ktn
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_exchange, args=(world, _free_port(), out), nprocs=world, join=True)
+    inst = ktn.instances.make_instance(n=800, m_nl=81, k=12, family="explog", seed=13)
+    x = np.clip(inst.xhat + 0.9, inst.l_var, inst.u_var)
+    full = _oracle_cut_block(inst, x)
+    assert len(full[3]) > 2
+    for rank in range(world):
+        blocks, empty_counts = out[rank]
+        assert empty_counts == [0, 0]
+        rp = np.concatenate([[0]] + [b[0][1:] + off for b, off in
+                                     zip(blocks, np.cumsum([0] + [len(b[1]) for b in blocks[:-1]]))])
+        col = np.concatenate([b[1] for b in blocks]); val = np.concatenate([b[2] for b in blocks])
+        lo = np.concatenate([b[3] for b in blocks]); hi = np.concatenate([b[4] for b in blocks])
+        # rank-ordered merge of contiguous row blocks == the single-process row order, bit for bit
+        assert np.array_equal(rp, full[0]) and np.array_equal(col, full[1]) and np.array_equal(val, full[2])
+        assert np.array_equal(lo, full[3]) and np.array_equal(hi, full[4])
+
+
+def test_shards_partition_the_nl_rows():
+    import katana_jl_amd as ktn
+    from katana_jl_amd.distributed import shard_bounds, shard_instance
+    inst = ktn.instances.make_instance(n=300, m_nl=37, k=8, family="quad", seed=1)
+    for world in (1, 2, 3, 8):
+        cover = []
+        for r in range(world):
+            lo, hi = shard_bounds(inst.m_nl, r, world)
+            cover += list(range(lo, hi))
+            s = shard_instance(inst, r, world)
+            assert s.m_lin == inst.m_lin and s.m_nl == hi - lo and s.num_constr == inst.m_lin + hi - lo
+            a, b = inst.rowptr[inst.m_lin + lo], inst.rowptr[inst.m_lin + hi]
+            assert np.array_equal(s.p0[s.rowptr[s.m_lin]:], inst.p0[a:b])
+            assert np.array_equal(s.u_constr[:s.m_lin], inst.u_constr[:inst.m_lin])
+        assert cover == list(range(inst.m_nl))
+
+
+def test_pack_unpack_roundtrip_with_empty_and_ragged_blocks():
+    from katana_jl_amd.distributed import pack_block, unpack_block
+    rng = np.random.default_rng(0)
+    for lens in ([], [3], [0, 5, 1], [2 ** 20 % 7, 40]):
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        nnz = int(rp[-1])
+        col = rng.integers(0, 2 ** 31 - 1, nnz).astype(np.int32)
+        val, lo, hi = rng.normal(size=nnz), np.full(len(lens), -np.inf), rng.normal(size=len(lens))
+        if len(lens):
+            hi[0] = np.nan
+        got = unpack_block(pack_block(rp, col, val, lo, hi), len(lens), nnz)
+        assert np.array_equal(got[0], rp) and np.array_equal(got[1], col) and np.array_equal(got[2], val)
+        assert np.array_equal(got[3], lo) and np.array_equal(got[4], hi, equal_nan=True)
+
+
+def _worker_gpu(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import katana_jl_amd as ktn
+    from katana_jl_amd.distributed import ShardedKatanaModel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    inst = ktn.instances.make_instance(n=4000, m_nl=400, k=16, family="explog", seed=21)
+    m = ShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0), inst, rank, world, dist)
+    st = m.optimize()
+    out[rank] = (st, m.getobjval(), m.numiters(), m.numcuts(), m.getsolution())
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_solve_matches_single_gpu():
+    import katana_jl_amd as ktn
+    from helpers import hip_load_instance, max_nl_violation
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker_gpu, args=(world, _free_port(), out), nprocs=world, join=True)
+    inst = ktn.instances.make_instance(n=4000, m_nl=400, k=16, family="explog", seed=21)
+    single = hip_load_instance(ktn, inst, lp_dual_inherit=0)
+    assert single.optimize() == "Optimal"
+    (s0, o0, it0, c0, x0), (s1, o1, it1, c1, x1) = out[0], out[1]
+    assert s0 == s1 == "Optimal"
+    assert o0 == o1 and it0 == it1 and c0 == c1 and np.array_equal(x0, x1)     # replicated LP: identical ranks
+    # rank-ordered contiguous blocks == single-process row order => the very same trajectory
+    assert o0 == single.getobjval() and it0 == single.numiters() and c0 == single.numcuts()
+    assert abs(o0 - inst.opt_obj) <= 1e-5 * max(1, abs(inst.opt_obj))
+    assert max_nl_violation(inst, x0) <= 1e-6 * (1 + 1e-6)
+
+
+@pytest.mark.gpu
+def test_sharded_model_world1_equals_engine_loop():
+    import katana_jl_amd as ktn
+    from helpers import hip_load_instance
+    from katana_jl_amd.distributed import ShardedKatanaModel
+    inst = ktn.instances.make_instance(n=2000, m_nl=200, k=16, family="quad", seed=5)
+    a = ShardedKatanaModel(ktn.KatanaSolver(log_level=0), inst, 0, 1, None)
+    assert a.optimize() == "Optimal"
+    b = hip_load_instance(ktn, inst, lp_dual_inherit=0)
+    assert b.optimize() == "Optimal"
+    assert a.getobjval() == b.getobjval() and a.numiters() == b.numiters() and a.numcuts() == b.numcuts()
