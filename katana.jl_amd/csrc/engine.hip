@@ -159,8 +159,10 @@ struct Engine {
     // ---- device NLP ----
     DBuf<int64_t> d_rowptr, d_nodeptr;
     DBuf<int32_t> d_col, d_nodeop, d_nodea, d_nodeb;
-    DBuf<uint8_t> d_akind, d_rowkind, d_padzero;
-    DBuf<double> d_p0, d_p1, d_rconst, d_lb, d_ub, d_nodec, d_nodeval, d_nodeadj;
+    DBuf<uint8_t> d_rowkind, d_padzero;
+    DBuf<int32_t> d_colk;
+    DBuf<double2> d_pp;
+    DBuf<double> d_rconst, d_lb, d_ub, d_nodec, d_nodeval, d_nodeadj;
     DBuf<int32_t> d_nlrows, d_allrows, d_taperows_all, d_taperows_nl;
     // sweep state
     DBuf<double> d_g, d_jac, d_bconst, d_maxc, d_xs, d_ray, d_scal;
@@ -282,7 +284,7 @@ struct Engine {
 
     NlpDev nlp_view() {
         NlpDev P;
-        P.rowptr = d_rowptr.p; P.col = d_col.p; P.akind = d_akind.p; P.p0 = d_p0.p; P.p1 = d_p1.p;
+        P.rowptr = d_rowptr.p; P.col = d_col.p; P.colk = d_colk.p; P.pp = d_pp.p;
         P.rconst = d_rconst.p; P.row_kind = d_rowkind.p; P.pad_zero = d_padzero.p; P.lb = d_lb.p; P.ub = d_ub.p;
         P.node_ptr = d_nodeptr.p; P.node_op = d_nodeop.p; P.node_a = d_nodea.p; P.node_b = d_nodeb.p;
         P.node_c = d_nodec.p; P.node_val = d_nodeval.p; P.node_adj = d_nodeadj.p;
@@ -448,7 +450,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     KTN_REQUIRE(d != nullptr, "nlp description is NULL");
     KTN_REQUIRE(num_var >= 0 && num_constr >= 0, "negative sizes");
     KTN_REQUIRE(d->num_var == num_var && d->num_constr == num_constr, "nlp description sizes disagree with loadproblem");
-    KTN_REQUIRE(num_var < (int64_t)0x7ffffff0, "num_var too large for 32-bit column indices");
+    KTN_REQUIRE(num_var + 1 < ((int64_t)1 << kKindShift), "num_var too large for the packed 29-bit column index");
     loaded = false;
     n0 = num_var; m0 = num_constr; sense = sense_;
     obj_linear = d->obj_linear != 0;
@@ -559,8 +561,19 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
         if (!std::isfinite(lv[j]) || !std::isfinite(uv[j])) has_inf_bound = true;
 
     // ---- upload the NLP
-    d_rowptr.upload(h_rowptr, stream); d_col.upload(h_col, stream); d_akind.upload(akind, stream);
-    d_p0.upload(p0, stream); d_p1.upload(p1, stream); d_rconst.upload(rconst, stream);
+    d_rowptr.upload(h_rowptr, stream); d_col.upload(h_col, stream);
+    {
+        std::vector<int32_t> colk(h_col.size());
+        std::vector<double2> pp(h_col.size());
+        for (size_t e = 0; e < h_col.size(); ++e) {
+            KTN_REQUIRE(akind[e] <= KTN_ATOM_NEGLOG, "unknown atom kind");
+            colk[e] = h_col[e] | ((int32_t)akind[e] << kKindShift);
+            pp[e] = make_double2(p0[e], p1[e]);
+        }
+        d_colk.upload(colk, stream);
+        d_pp.upload(pp, stream);
+    }
+    d_rconst.upload(rconst, stream);
     d_rowkind.upload(h_rowkind, stream); d_padzero.upload(padzero, stream);
     d_lb.upload(h_lb, stream); d_ub.upload(h_ub, stream);
     d_nodeptr.upload(nodeptr, stream); d_nodeop.upload(nop, stream); d_nodea.upload(na, stream);
@@ -582,7 +595,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     grp_sweep = pick_group(m_nl ? (double)nnz_nl / (double)m_nl : 4.0);
     if (grp_sweep < 8) grp_sweep = 8;
     // algorithmic bytes of one evaluation pass over the NL rows (DESIGN.md "sweep bytes")
-    sweep_bytes = (double)nnz_nl * (4 + 1 + 16) + 8.0 * (m_nl + 1) + 8.0 * n_lp + 8.0 * 4 * m_nl + 16.0 * m_nl;
+    sweep_bytes = (double)nnz_nl * (4 + 16) + 8.0 * (m_nl + 1) + 8.0 * n_lp + 8.0 * 4 * m_nl + 16.0 * m_nl;
     const size_t mm = (size_t)std::max<int64_t>(m_ext, 1);
     d_g.resize(mm, stream); d_bconst.resize(mm, stream); d_maxc.resize(mm, stream); d_nonfin.resize(mm, stream);
     d_jac.resize((size_t)nnz_ext + 1, stream);

@@ -24,6 +24,8 @@ namespace ktn {
 constexpr int kBlock = 256;
 constexpr int kRedBlocks = 256;   // blocks of the two-stage deterministic reductions
 constexpr int kChkQ = 16;         // quantities per check partial
+constexpr int kKindShift = 29;    // packed (col | kind << 29): columns < 2^29
+constexpr int kColMask = (1 << kKindShift) - 1;
 
 // ---------------------------------------------------------------- small helpers ----
 template <int G>
@@ -75,9 +77,9 @@ __device__ __forceinline__ void atom_eval(int kind, double a, double b, double x
 struct NlpDev {
     const int64_t* rowptr;
     const int32_t* col;
-    const uint8_t* akind;
-    const double* p0;
-    const double* p1;
+    // separable atoms, packed for the sweep: 20 B per Jacobian entry in two coalesced streams
+    const int32_t* colk;     // col | kind << 29
+    const double2* pp;       // (p0, p1)
     const double* rconst;
     const uint8_t* row_kind;
     const uint8_t* pad_zero;   // row has implicit zero coefficients (dense epigraph row, src/nlpeval.jl:49-54)
@@ -119,16 +121,34 @@ __global__ __launch_bounds__(kBlock) void k_sep_eval(NlpDev P, const int32_t* __
     const int64_t beg = P.rowptr[r], end = P.rowptr[r + 1];
     double acc_g = 0.0, acc_dot = 0.0, mx = -__builtin_inf();
     int nf = 0;
-    for (int64_t e = beg + lane; e < end; e += G) {
-        const int c = P.col[e];
-        double val, der;
-        const double xv = x[c];
-        atom_eval(P.akind[e], P.p0[e], P.p1[e], xv, val, der);
-        acc_g += val;
-        acc_dot += xv * der;
-        mx = nanmax(mx, der);
-        nf |= !isfinite(der);
-        if (materialize) O.jac[e] = der;
+    // kU entries per lane and trip: all (colk, pp) loads and all x gathers of a trip are issued
+    // before any arithmetic, so each wavefront keeps kU * G * 20 B (+ gathers) in flight
+    constexpr int kU = 2;
+    for (int64_t e = beg + lane; e < end; e += kU * G) {
+        int ck[kU];
+        double2 q[kU];
+        double xv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int64_t eu = e + (int64_t)u * G;
+            const bool on = eu < end;
+            ck[u] = on ? P.colk[eu] : -1;
+            q[u] = on ? P.pp[eu] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) xv[u] = (ck[u] >= 0) ? x[ck[u] & kColMask] : 0.0;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (ck[u] >= 0) {
+                double val, der;
+                atom_eval((unsigned)ck[u] >> kKindShift, q[u].x, q[u].y, xv[u], val, der);
+                acc_g += val;
+                acc_dot += xv[u] * der;
+                mx = nanmax(mx, der);
+                nf |= !isfinite(der);
+                if (materialize) O.jac[e + (int64_t)u * G] = der;
+            }
+        }
     }
     acc_g = group_sum<G>(acc_g);
     acc_dot = group_sum<G>(acc_dot);
@@ -309,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void k_emit(NlpDev P, const int32_t* __rest
     for (int64_t e = beg + lane; e < end; e += G) {
         const int c = P.col[e];
         double der;
-        if (sep) { double val; atom_eval(P.akind[e], P.p0[e], P.p1[e], x[c], val, der); }
+        if (sep) { double val; const double2 q = P.pp[e]; atom_eval((unsigned)P.colk[e] >> kKindShift, q.x, q.y, x[c], val, der); }
         else der = jac[e];
         if (round_coefs && (der + cut_coef_rng < mx)) der = 0.0;   // model.jl:202-206 (signed max)
         L.col[dst + (e - beg)] = c;
