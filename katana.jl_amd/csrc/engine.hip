@@ -167,7 +167,8 @@ struct Engine {
     // sweep state
     DBuf<double> d_g, d_jac, d_bconst, d_maxc, d_xs, d_ray, d_scal;
     DBuf<int32_t> d_nonfin, d_violslots, d_anynf;
-    DBuf<int64_t> d_flag, d_cnt, d_rank, d_cntscan, d_lastcut;
+    DBuf<int64_t> d_flag, d_cnt, d_rank, d_cntscan, d_lastcut, d_cutprev;
+    DBuf<double> d_ones;
     DBuf<char> d_scantmp;
     bool have_precompute = false;
 
@@ -179,6 +180,7 @@ struct Engine {
     int64_t M = 0, NNZ = 0, M_base = 0, NNZ_base = 0;
     int64_t numcuts = 0, numcuts_base = 0;
     bool lp_dirty = true;
+    bool sharded_rows = false;   // rows were appended/truncated from the host: cut lists are not tracked
     // CSC mirror + scaling + PDHG workspace
     DBuf<int64_t> c_ptr, c_cnt;
     DBuf<int32_t> c_row;
@@ -371,12 +373,13 @@ struct Engine {
             lp_lo.resize((size_t)(M + V), stream);
             lp_hi.resize((size_t)(M + V), stream);
             lp_y.resize((size_t)(M + V), stream);
+            d_cutprev.resize((size_t)(M + V), stream);
             lp_col.resize((size_t)(NNZ + nnzV), stream);
             lp_val.resize((size_t)(NNZ + nnzV), stream);
             d_violslots.resize((size_t)V, stream);
             LpRows L = lp_view();
             LAUNCH_1(k_compact, m_nl, stream, P, d_nlrows.p, m_nl, d_flag.p, d_rank.p, d_cntscan.p, d_bconst.p, M, NNZ, L,
-                     d_violslots.p, d_lastcut.p, (int)prm.lp_dual_inherit);
+                     d_violslots.p, d_lastcut.p, d_cutprev.p, (int)prm.lp_dual_inherit);
             LAUNCH_G(grp_sweep, k_emit, V, stream, P, d_nlrows.p, d_violslots.p, V, d_x, d_jac.p, d_maxc.p,
                      prm.cut_coef_rng, 1, M, L);
             check_launch();
@@ -703,7 +706,7 @@ void Engine::reset() {
     lp_y.zero(stream); lp_x.zero(stream);
     std::vector<int64_t> neg1((size_t)std::max<int64_t>(m_ext, 1), -1);
     d_lastcut.upload(neg1, stream);
-    lp_dirty = true; have_omega = false; have_precompute = false;
+    lp_dirty = true; have_omega = false; have_precompute = false; sharded_rows = false;
     status = KTN_STATUS_NONE; lp_status = KTN_STATUS_OPTIMAL;
     iter = 0; soltime = 0.0; objval = std::numeric_limits<double>::quiet_NaN();
     last_maxviol = 1e300; obj_prev = kInf; allsat = false; begun = false; tight_done = false;
@@ -784,11 +787,15 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
     SpMat A{lp_rowptr.p, lp_col.p, r_sval.p};
     SpMat AT{c_ptr.p, c_row.p, c_sval.p};
 
-    // step size: power iteration on A^'A^
+    // Step size eta = 0.998 / sigma_max(A^).  sigma_max comes from 20 power iterations (hashed start
+    // vector: a constant one can be orthogonal to every row).  The power iteration approaches sigma_max
+    // from BELOW, and an estimate a few percent low makes PDHG stall in a limit cycle (seen on dense
+    // epigraph cuts: constant fixed-point residual, 8e-6 row violation), so the main loop watches for
+    // that stall and backs eta off towards eta_safe.  With the Pock-Chambolle (alpha = 1) pass applied
+    // last ||A^||_2 <= 1 is guaranteed (Pock & Chambolle 2011, Lemma 2): eta_safe = 0.998; always using
+    // it costs 40 % (cfg3) to 170 % (cfg2) more PDHG iterations than the estimate.
     double smax = 0.0;
     if (m > 0 && NNZ > 0) {
-        // deterministic pseudo-random start (a constant vector can be orthogonal to every row,
-        // e.g. the single epigraph cut t - x >= 1)
         LAUNCH_1(k_hash_fill, n, stream, n, pv.p);
         double vnorm = std::sqrt(dev_dot(n, pv.p, pv.p));
         for (int it = 0; it < 20; ++it) {
@@ -801,8 +808,12 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
             vnorm = 1.0;
         }
     }
-    if (!(smax > 0.0) && NNZ > 0) smax = std::sqrt(dev_dot(NNZ, r_sval.p, r_sval.p));   // ||A||_2 <= ||A||_F
-    const double eta = 0.998 / std::max(smax, 1e-12);
+    const double fro = (NNZ > 0) ? std::sqrt(dev_dot(NNZ, r_sval.p, r_sval.p)) : 0.0;   // ||A||_2 <= ||A||_F
+    if (!(smax > 0.0)) smax = fro;
+    const double eta_safe = 0.998 / std::max(identity_scaling ? fro : std::min(1.0, fro), 1e-12);
+    double eta = std::max(0.998 / std::max(smax, 1e-12), eta_safe);
+    int stall = 0, flat_rows = 0, consolidations = 0;
+    double r_last_check = 0.0;
     const double nc2 = dev_dot(n, ch.p, ch.p);
     const double nb2 = (m > 0) ? dev_finite_sq(m, loh.p) + dev_finite_sq(m, hih.p) : 0.0;
     const double omega_ref = (nc2 > 0.0 && nb2 > 0.0) ? std::sqrt(nc2 / nb2) : 1.0;
@@ -873,7 +884,47 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
             ++it;
             break;
         }
-        const bool restart = k > 0 && (r <= 0.2 * r0 || (r <= 0.8 * r0 && r > r_prev) || (double)k >= 0.36 * (double)(it + 1));
+        bool restart = k > 0 && (r <= 0.2 * r0 || (r <= 0.8 * r0 && r > r_prev) || (double)k >= 0.36 * (double)(it + 1));
+        // step-size safeguard: a fixed-point residual that no longer moves (or a negative M-norm) while
+        // the LP is not solved means eta * sigma_max > 1 -> shrink eta and restart from the current point
+        if (k > 0 && eta > eta_safe * (1.0 + 1e-12)) {
+            stall = (r2 < 0.0 || (r_last_check > 0.0 && r > 0.97 * r_last_check && r < 1.03 * r_last_check)) ? stall + 1 : 0;
+            if (stall >= 3 || r2 < 0.0) {
+                eta = std::max(eta_safe, 0.85 * eta);
+                stall = 0;
+                restart = true;
+                stats["lp_eta_backoffs"] += 1.0;
+            }
+        }
+        // objective converged, rows not, residual flat: PDHG is idling between near-parallel cuts of one
+        // NL row (k_consolidate).  Move the multiplier mass onto the tightest cut at the current point and
+        // restart from there.
+        if (mode == 0 && k > 0 && prm.lp_dual_inherit && !sharded_rows && m_nl > 0 && m > M_base && gap <= tol_g &&
+            dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2)) && pviol > tol_p) {
+            flat_rows = (r_last_check > 0.0 && r > 0.98 * r_last_check) ? flat_rows + 1 : 0;
+            if (flat_rows >= 3 && consolidations < 8) {
+                flat_rows = 0;
+                ++consolidations;
+                stats["lp_consolidations"] += 1.0;
+                LAUNCH_1(k_unscale, n, stream, n, xth.p, dc.p, pv.p);
+                SpMat Au{lp_rowptr.p, lp_col.p, lp_val.p};
+                LAUNCH_G(grp_rows, k_spmv, m, stream, m, Au, pv.p, pw.p);
+                KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
+                LAUNCH_1(k_consolidate, m_nl, stream, m_nl, d_lastcut.p, d_cutprev.p, pw.p, lp_lo.p, lp_hi.p, dr.p, tol_p, yth.p,
+                         d_anynf.p + 1);
+                KTN_HIP(hipMemcpyAsync(xh.p, xth.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                KTN_HIP(hipMemcpyAsync(x0h.p, xth.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                KTN_HIP(hipMemcpyAsync(yh.p, yth.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                KTN_HIP(hipMemcpyAsync(y0h.p, yth.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                k = 0;
+                r_last_check = 0.0;
+                ++it;
+                continue;
+            }
+        } else {
+            flat_rows = 0;
+        }
+        r_last_check = r;
         r_prev = r;
         if (restart) {
             const double dx = std::sqrt(dx0sq), dy = std::sqrt(dy0sq);
@@ -1080,7 +1131,7 @@ void ktn_default_params(ktn_params* p) {
     p->f_tol = 1e-6; p->cut_coef_rng = 1e9; p->log_level = 10; p->iter_cap = 10000; p->obj_eps = -1.0;
     p->vis_data = 0; p->device = -1;
     p->lp_max_iter = 2000000; p->lp_check_every = 64; p->lp_ruiz_iters = 10;
-    p->lp_tol_scale = 0.1; p->lp_tol_floor = 0.3; p->lp_tol_cap = 1e-3; p->lp_gap_floor = 1e-7; p->lp_gap_cap = 1e-4;
+    p->lp_tol_scale = 0.1; p->lp_tol_floor = 0.3; p->lp_tol_cap = 0.1; p->lp_gap_floor = 1e-7; p->lp_gap_cap = 1e-2;
     p->lp_dual_inherit = 1; p->profile = 0;
 }
 
@@ -1356,6 +1407,7 @@ int ktn_lp_truncate(ktn_handle h, int64_t nrows) {
         e->sync();
         e->numcuts -= (e->M - nrows);
         e->M = nrows; e->NNZ = base;
+        e->sharded_rows = true;
         e->lp_rowptr.n = (size_t)nrows + 1; e->lp_col.n = e->lp_val.n = (size_t)base;
         e->lp_lo.n = e->lp_hi.n = e->lp_y.n = (size_t)nrows;
         e->lp_dirty = true;
@@ -1390,6 +1442,7 @@ int ktn_lp_append_rows(ktn_handle h, int64_t nrows, const int64_t* rowptr, const
         }
         e->sync();
         e->M += nrows; e->NNZ += nz; e->numcuts += nrows;
+        e->sharded_rows = true;
         e->lp_dirty = true;
         return KTN_OK;
     })

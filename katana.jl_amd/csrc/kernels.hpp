@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(NlpDev P, const int32_t* __r
                                                     const int64_t* __restrict__ cnt_scan, const double* __restrict__ bconst,
                                                     int64_t base_row, int64_t base_nnz, LpRows L,
                                                     int32_t* __restrict__ viol_slots, int64_t* __restrict__ last_cut,
-                                                    int inherit) {
+                                                    int64_t* __restrict__ cut_prev, int inherit) {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= m_nl) return;
     if (!flag[gid]) return;
@@ -308,7 +308,44 @@ __global__ __launch_bounds__(kBlock) void k_compact(NlpDev P, const int32_t* __r
     const int64_t prev = last_cut[gid];
     if (inherit && prev >= 0) { y0 = L.y[prev]; L.y[prev] = 0.0; }
     L.y[R] = y0;
+    cut_prev[R] = prev;      // linked list of the cuts of this NL row, newest first (k_consolidate)
     last_cut[gid] = R;
+}
+
+// Dual-mass consolidation among the cuts of ONE nonlinear row (stall handler of the GPU LP).
+// Near the optimum successive cuts of a row are nearly parallel; PDHG moves multiplier mass between
+// two of them only at a rate proportional to the (tiny) violation and idles with the iterate stuck
+// between the two: one cut violated by eps, the other slack by eps and still holding the mass.  By
+// complementary slackness a cut that is slack at the (objective-converged) point carries no multiplier:
+// move the mass of every cut of the row that is slack by more than `thresh` onto the row's tightest
+// cut (unscaled duals, so A'y changes only by mass * (difference of two nearly equal rows)).  Cuts
+// that are tight keep their multipliers, so a vertex formed by several cuts of one row is untouched.
+// One thread per NL slot walks that slot's list; sequential => deterministic.
+__global__ __launch_bounds__(kBlock) void k_consolidate(int64_t m_nl, const int64_t* __restrict__ last_cut,
+                                                        const int64_t* __restrict__ cut_prev, const double* __restrict__ ax,
+                                                        const double* __restrict__ lo, const double* __restrict__ hi,
+                                                        const double* __restrict__ dr, double thresh,
+                                                        double* __restrict__ y, int32_t* __restrict__ moved) {
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= m_nl) return;
+    int64_t best_u = -1, best_l = -1;
+    double res_u = -__builtin_inf(), res_l = -__builtin_inf();
+    int ncuts = 0;
+    for (int64_t r = last_cut[s]; r >= 0; r = cut_prev[r]) {
+        ++ncuts;
+        const double ru = ax[r] - hi[r], rl = lo[r] - ax[r];      // -inf on an infinite side, NaN on a vacuous one
+        if (ru > res_u) { res_u = ru; best_u = r; }
+        if (rl > res_l) { res_l = rl; best_l = r; }
+    }
+    if (ncuts < 2) return;
+    double mass_u = 0.0, mass_l = 0.0;                             // unscaled multipliers: y_unscaled = y * dr
+    for (int64_t r = last_cut[s]; r >= 0; r = cut_prev[r]) {
+        const double yu = y[r] * dr[r];
+        if (yu < 0.0 && best_u >= 0 && r != best_u && (ax[r] - hi[r]) < -thresh) { mass_u += yu; y[r] = 0.0; }
+        else if (yu > 0.0 && best_l >= 0 && r != best_l && (lo[r] - ax[r]) < -thresh) { mass_l += yu; y[r] = 0.0; }
+    }
+    if (mass_u != 0.0) { y[best_u] += mass_u / dr[best_u]; atomicAdd(moved, 1); }
+    if (mass_l != 0.0) { y[best_l] += mass_l / dr[best_l]; atomicAdd(moved, 1); }
 }
 
 // gencut + round_coefs + row append: G lanes per violated row.
@@ -583,6 +620,12 @@ __global__ __launch_bounds__(kBlock) void k_unscale(int64_t n, const double* __r
                                                     double* __restrict__ z) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) z[i] = zh[i] * d[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_div_vec(int64_t n, const double* __restrict__ a, const double* __restrict__ d,
+                                                    double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = a[i] / d[i];
 }
 
 // ---------------------------------------------------------- generic vector ops ----
