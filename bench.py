@@ -13,8 +13,9 @@ the timed region (ktn_loadproblem copies them once).
 
 Prints ONE JSON line (rank 0).  `value` = ECP iterations / second, whole job.
   roofline     -- the dominant kernel (k_pdhg_y: the A x SpMV + dual prox of the GPU LP), algorithmic
-                  bytes per launch / mean launch duration measured with hipEvents on the engine's own
-                  stream in a second, identical pass over the same K steps (profile=1).
+                  bytes per launch / mean launch duration from the start/stop hipEvents of
+                  hipExtLaunchKernelGGL on the engine's own stream, in a second, identical pass over the
+                  same K steps (profile=1).
   cpu_baseline -- the CPU oracle (serial restatement of the reference + HiGHS dual simplex, 1 core)
                   on a bounded sample: the same family at half scale, full solve to f_tol.
 """
@@ -185,6 +186,13 @@ def main():
                     "timing": "per launch, hipExtLaunchKernelGGL start/stop hipEvents on the engine's own stream "
                               "(the dispatch's begin/end timestamps, as rocprofv3 --kernel-trace reports them)"}
         roofline = rf("ky", "k_pdhg_y (A x SpMV + dual prox + Halpern update)")
+        # HBM traffic from the PMC counters cannot be collected in-process; the per-launch figure of the
+        # committed rocprofv3 --pmc passes over this same command is reported (profiles/r01_traffic.json)
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and args.workload == "cfg3":
+            t = json.load(open(tpath))
+            roofline["traffic"] = t["k_pdhg_y"]["bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; raw sum, see its _note)"
         roofline["other_kernels"] = {
             "k_pdhg_x": rf("kx", "k_pdhg_x (A'y SpMV + primal prox + Halpern update)"),
             "k_sep_eval": rf("sweep_eval", "k_sep_eval (separator sweep: g, cut constant, violation)"),
