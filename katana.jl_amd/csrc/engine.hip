@@ -190,6 +190,9 @@ struct Engine {
     DBuf<char> d_sorttmp;
     DBuf<double> dr, dc, statr, statc, ch, lh, uh, loh, hih, xh, yh, x0h, y0h, xth, yth, xbar, pv, pw, box;
     DBuf<double> partials, chkout;
+    DBuf<int32_t> d_longrows;
+    int64_t n_long = 0;
+    static constexpr int64_t kLongRow = 2048;
     double omega = 1.0;
     bool have_omega = false;
     int grp_rows = 8, grp_cols = 8;
@@ -395,6 +398,9 @@ struct Engine {
 
     // ================================================================ LP ============
     void rebuild_csc();
+    void find_long_rows();
+    template <bool UPDATE>
+    void launch_y(const SpMat& A, double sigma, double w, double rho, hipEvent_t e0, hipEvent_t e1);
     void compute_scaling(bool identity);
     LpResult lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling = false);
     void pdhg_raw(const double* x0, const double* y0, double eta, double omega_, int64_t iters, double* x_out,
@@ -726,7 +732,8 @@ void Engine::rebuild_csc() {
     if (NNZ > 0) {
         k_in.resize((size_t)NNZ, stream); k_out.resize((size_t)NNZ, stream);
         p_in.resize((size_t)NNZ, stream); p_out.resize((size_t)NNZ, stream);
-        LAUNCH_1(k_csc_keys, M, stream, M, lp_rowptr.p, lp_col.p, k_in.p, p_in.p, c_cnt.p);
+        LAUNCH_G(pick_group((double)NNZ / (double)std::max<int64_t>(M, 1)), k_csc_keys, M, stream, M, lp_rowptr.p, lp_col.p, k_in.p,
+                 p_in.p, c_cnt.p);
         check_launch();
     }
     exclusive_scan(c_cnt.p, c_ptr.p, (size_t)n_lp + 1);
@@ -749,20 +756,46 @@ void Engine::compute_scaling(bool identity) {
     statc.resize((size_t)n_lp, stream);
     LAUNCH_1(k_fill, M, stream, M, dr.p, 1.0);
     LAUNCH_1(k_fill, n_lp, stream, n_lp, dc.p, 1.0);
+    const int gr = pick_group((double)NNZ / (double)std::max<int64_t>(M, 1));
+    const int gc = pick_group((double)NNZ / (double)std::max<int64_t>(n_lp, 1));
     if (!identity && M > 0) {
         for (int it = 0; it <= prm.lp_ruiz_iters; ++it) {
             const int mode = (it == prm.lp_ruiz_iters) ? 1 : 0;   // last pass: Pock-Chambolle (alpha = 1)
-            LAUNCH_1(k_scale_stat, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, mode, statr.p);
-            LAUNCH_1(k_scale_stat, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, statc.p);
+            LAUNCH_G(gr, k_scale_stat, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, mode, statr.p);
+            LAUNCH_G(gc, k_scale_stat, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, statc.p);
             LAUNCH_1(k_scale_apply, M, stream, M, dr.p, statr.p);
             LAUNCH_1(k_scale_apply, n_lp, stream, n_lp, dc.p, statc.p);
         }
     }
     r_sval.resize((size_t)NNZ + 1, stream);
     c_sval.resize((size_t)NNZ + 1, stream);
-    LAUNCH_1(k_scale_vals, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, r_sval.p);
-    LAUNCH_1(k_scale_vals, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, c_sval.p);
+    LAUNCH_G(gr, k_scale_vals, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, r_sval.p);
+    LAUNCH_G(gc, k_scale_vals, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, c_sval.p);
     check_launch();
+}
+
+void Engine::find_long_rows() {
+    n_long = 0;
+    if (M == 0) return;
+    d_longrows.resize((size_t)M, stream);
+    KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
+    LAUNCH_1(k_find_long, M, stream, M, lp_rowptr.p, kLongRow, d_longrows.p, d_anynf.p + 1);
+    int32_t cnt = 0;
+    KTN_HIP(hipMemcpyAsync(&cnt, d_anynf.p + 1, 4, hipMemcpyDeviceToHost, stream));
+    sync();
+    n_long = cnt;
+}
+
+// y-step over all rows: G lanes per row for ordinary rows, a workgroup per row for the long ones
+template <bool UPDATE>
+void Engine::launch_y(const SpMat& A, double sigma, double w, double rho, hipEvent_t e0, hipEvent_t e1) {
+    const int64_t m = M;
+    const int64_t thr = n_long > 0 ? kLongRow : (int64_t)1 << 62;
+    if (e0) LAUNCH_GB_EV(grp_rows, k_pdhg_y, UPDATE, m, stream, e0, e1, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, rho, thr);
+    else LAUNCH_GB(grp_rows, k_pdhg_y, UPDATE, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, rho, thr);
+    if (n_long > 0)
+        hipLaunchKernelGGL((k_pdhg_y_long<UPDATE>), dim3((unsigned)n_long), dim3(kLongBlock), 0, stream, d_longrows.p, A, xbar.p, yh.p,
+                           y0h.p, yth.p, loh.p, hih.p, sigma, w, rho);
 }
 
 LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling) {
@@ -786,6 +819,7 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
     grp_cols = pick_group(avg_c);
     SpMat A{lp_rowptr.p, lp_col.p, r_sval.p};
     SpMat AT{c_ptr.p, c_row.p, c_sval.p};
+    find_long_rows();
 
     // Step size eta = 0.998 / sigma_max(A^).  sigma_max comes from 20 power iterations (hashed start
     // vector: a constant one can be orthogonal to every row).  The power iteration approaches sigma_max
@@ -841,22 +875,21 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
                 const size_t e0 = ev_get(), e1 = ev_get(), e2 = ev_get(), e3 = ev_get();
                 LAUNCH_GB_EV(grp_cols, k_pdhg_x, true, n, stream, ev_pool[e0], ev_pool[e1], n, AT, yh.p, xh.p, x0h.p, xth.p,
                              xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
-                LAUNCH_GB_EV(grp_rows, k_pdhg_y, true, m, stream, ev_pool[e2], ev_pool[e3], m, A, xbar.p, yh.p, y0h.p, yth.p,
-                             loh.p, hih.p, sigma, w, rho);
+                launch_y<true>(A, sigma, w, rho, ev_pool[e2], ev_pool[e3]);
                 ev_recs.push_back({0, e0, e1, kx_bytes});
                 if (m > 0) ev_recs.push_back({1, e2, e3, ky_bytes});
             } else {
                 LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
-                LAUNCH_GB(grp_rows, k_pdhg_y, true, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, rho);
+                launch_y<true>(A, sigma, w, rho, nullptr, nullptr);
             }
             ++k; ++it;
             continue;
         }
         // ---- check iteration: PDHG step without update, KKT + fixed-point residual
         LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, 0.0, rho);
-        LAUNCH_GB(grp_rows, k_pdhg_y, false, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, 0.0, rho);
+        launch_y<false>(A, sigma, 0.0, rho, nullptr, nullptr);
         hipLaunchKernelGGL(k_chk_rows, dim3(kRedBlocks), dim3(kBlock), 0, stream, m, A, xh.p, xth.p, yh.p, yth.p, y0h.p,
-                           loh.p, hih.p, dr.p, partials.p);
+                           loh.p, hih.p, dr.p, d_longrows.p, n_long, (n_long > 0 ? kLongRow : (int64_t)1 << 62), partials.p);
         hipLaunchKernelGGL(k_chk_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, chkout.p);
         hipLaunchKernelGGL(k_chk_cols, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, AT, xh.p, xth.p, x0h.p, yth.p, ch.p,
                            lh.p, uh.p, dc.p, partials.p + (size_t)kRedBlocks * kChkQ);
@@ -989,11 +1022,12 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
     SpMat AT{c_ptr.p, c_row.p, c_sval.p};
     KTN_HIP(hipMemcpyAsync(x0h.p, xh.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     if (m > 0) KTN_HIP(hipMemcpyAsync(y0h.p, yh.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    find_long_rows();
     const double tau = eta / omega_, sigma = eta * omega_;
     for (int64_t k = 0; k < iters; ++k) {
         const double w = (double)(k + 1) / (double)(k + 2);
         LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, 1.0);
-        LAUNCH_GB(grp_rows, k_pdhg_y, true, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, 1.0);
+        launch_y<true>(A, sigma, w, 1.0, nullptr, nullptr);
     }
     check_launch();
     KTN_HIP(hipMemcpyAsync(x_out, xh.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));

@@ -413,11 +413,13 @@ template <int G, bool UPDATE>
 __global__ __launch_bounds__(kBlock) void k_pdhg_y(int64_t m, SpMat A, const double* __restrict__ xbar,
                                                    double* __restrict__ y, const double* __restrict__ y0,
                                                    double* __restrict__ yt, const double* __restrict__ lo,
-                                                   const double* __restrict__ hi, double sigma, double w, double rho) {
+                                                   const double* __restrict__ hi, double sigma, double w, double rho,
+                                                   int64_t long_thresh) {
     const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     if (i >= m) return;
     const int64_t beg = A.ptr[i], end = A.ptr[i + 1];
+    if (end - beg > long_thresh) return;          // served by k_pdhg_y_long (a workgroup per row)
     double acc = 0.0;
     for (int64_t e = beg + lane; e < end; e += G) acc += A.val[e] * xbar[A.idx[e]];
     acc = group_sum<G>(acc);
@@ -428,6 +430,40 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_y(int64_t m, SpMat A, const dou
         if (UPDATE) y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0[i];
         else yt[i] = ytv;
     }
+}
+
+// Long rows (dense epigraph cuts: n+1 entries): one 256-thread workgroup per row, fixed-shape
+// reduction (butterfly per wavefront, then 4 partials through LDS) => deterministic.
+constexpr int kLongBlock = 1024;
+template <bool UPDATE>
+__global__ __launch_bounds__(kLongBlock) void k_pdhg_y_long(const int32_t* __restrict__ rows, SpMat A,
+                                                        const double* __restrict__ xbar, double* __restrict__ y,
+                                                        const double* __restrict__ y0, double* __restrict__ yt,
+                                                        const double* __restrict__ lo, const double* __restrict__ hi,
+                                                        double sigma, double w, double rho) {
+    const int64_t i = rows[blockIdx.x];
+    const int64_t beg = A.ptr[i], end = A.ptr[i + 1];
+    double acc = 0.0;
+    for (int64_t e = beg + threadIdx.x; e < end; e += kLongBlock) acc += A.val[e] * xbar[A.idx[e]];
+    __shared__ double sh[kLongBlock / 64];
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ax = 0.0;
+        for (int k = 0; k < kLongBlock / 64; ++k) ax += sh[k];
+        const double yv = y[i];
+        const double v = yv - sigma * ax;
+        const double ytv = v + sigma * clampd(-v / sigma, lo[i], hi[i]);
+        if (UPDATE) y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0[i];
+        else yt[i] = ytv;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_find_long(int64_t m, const int64_t* __restrict__ rowptr, int64_t thresh,
+                                                      int32_t* __restrict__ list, int32_t* __restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    if (rowptr[i + 1] - rowptr[i] > thresh) list[atomicAdd(count, 1)] = (int32_t)i;
 }
 
 // Halpern update after a check iteration that neither terminated nor restarted.
@@ -487,13 +523,29 @@ __global__ __launch_bounds__(kRedBlocks) void k_chk_final(const double* __restri
 // iterations run once per `lp_check_every` PDHG iterations and are not the hot kernel).
 //  s0 sum dy*(A dx)   s1 sum dy^2      s2 dual objective (rows)  s3 sum (yt-y0)^2  s4 sum yt^2
 //  m12 max unscaled row violation
+__device__ __forceinline__ void chk_row_accumulate(ChkAcc& a, int64_t i, double axt, double axk, const double* y,
+                                                   const double* yt, const double* y0, const double* lo, const double* hi,
+                                                   const double* dr) {
+    const double ytv = yt[i], dy = ytv - y[i];
+    a.s[0] += dy * (axt - axk);
+    a.s[1] += dy * dy;
+    if (ytv > 0.0) a.s[2] += lo[i] * ytv;        // lo finite whenever yt > 0 (prox keeps y <= 0 otherwise)
+    else if (ytv < 0.0) a.s[2] += hi[i] * ytv;
+    const double d0 = ytv - y0[i];
+    a.s[3] += d0 * d0;
+    a.s[4] += ytv * ytv;
+    const double viol = fmax(fmax(lo[i] - axt, axt - hi[i]), 0.0) / dr[i];
+    a.s[12] = fmax(a.s[12], viol);
+}
 __global__ __launch_bounds__(kBlock) void k_chk_rows(int64_t m, SpMat A, const double* __restrict__ x,
                                                      const double* __restrict__ xt, const double* __restrict__ y,
                                                      const double* __restrict__ yt, const double* __restrict__ y0,
                                                      const double* __restrict__ lo, const double* __restrict__ hi,
-                                                     const double* __restrict__ dr, double* __restrict__ partials) {
+                                                     const double* __restrict__ dr, const int32_t* __restrict__ long_rows,
+                                                     int64_t n_long, int64_t long_thresh, double* __restrict__ partials) {
     ChkAcc a; a.init();
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+        if (A.ptr[i + 1] - A.ptr[i] > long_thresh) continue;
         double axt = 0.0, axk = 0.0;
         for (int64_t e = A.ptr[i]; e < A.ptr[i + 1]; ++e) {
             const int c = A.idx[e];
@@ -501,16 +553,29 @@ __global__ __launch_bounds__(kBlock) void k_chk_rows(int64_t m, SpMat A, const d
             axt += v * xt[c];
             axk += v * x[c];
         }
-        const double ytv = yt[i], dy = ytv - y[i];
-        a.s[0] += dy * (axt - axk);
-        a.s[1] += dy * dy;
-        if (ytv > 0.0) a.s[2] += lo[i] * ytv;        // lo finite whenever yt > 0 (prox keeps y <= 0 otherwise)
-        else if (ytv < 0.0) a.s[2] += hi[i] * ytv;
-        const double d0 = ytv - y0[i];
-        a.s[3] += d0 * d0;
-        a.s[4] += ytv * ytv;
-        const double viol = fmax(fmax(lo[i] - axt, axt - hi[i]), 0.0) / dr[i];
-        a.s[12] = fmax(a.s[12], viol);
+        chk_row_accumulate(a, i, axt, axk, y, yt, y0, lo, hi, dr);
+    }
+    // long rows: the whole workgroup reduces one row at a time
+    __shared__ double sh2[2][kBlock / 64];
+    for (int64_t li = blockIdx.x; li < n_long; li += gridDim.x) {
+        const int64_t i = long_rows[li];
+        double axt = 0.0, axk = 0.0;
+        for (int64_t e = A.ptr[i] + threadIdx.x; e < A.ptr[i + 1]; e += kBlock) {
+            const int c = A.idx[e];
+            const double v = A.val[e];
+            axt += v * xt[c];
+            axk += v * x[c];
+        }
+        axt = group_sum<64>(axt);
+        axk = group_sum<64>(axk);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { sh2[0][threadIdx.x >> 6] = axt; sh2[1][threadIdx.x >> 6] = axk; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double st = 0.0, sk = 0.0;
+            for (int k = 0; k < kBlock / 64; ++k) { st += sh2[0][k]; sk += sh2[1][k]; }
+            chk_row_accumulate(a, i, st, sk, y, yt, y0, lo, hi, dr);
+        }
     }
     chk_block_store(a, partials);
 }
@@ -545,18 +610,21 @@ __global__ __launch_bounds__(kBlock) void k_chk_cols(int64_t n, SpMat AT, const 
 // Ruiz / Pock-Chambolle passes on the UNSCALED matrix with the current dr, dc:
 //   mode 0: out_i = dr_i * max_e |a_e| dc_col(e)     mode 1: out_i = dr_i * sum_e |a_e| dc_col(e)
 // (the same kernel serves columns through the CSC mirror with the roles of dr/dc swapped)
+template <int G>
 __global__ __launch_bounds__(kBlock) void k_scale_stat(int64_t m, const int64_t* __restrict__ ptr,
                                                        const int32_t* __restrict__ idx, const double* __restrict__ val,
                                                        const double* __restrict__ dself, const double* __restrict__ dother,
                                                        int mode, double* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
     if (i >= m) return;
     double acc = 0.0;
-    for (int64_t e = ptr[i]; e < ptr[i + 1]; ++e) {
+    for (int64_t e = ptr[i] + lane; e < ptr[i + 1]; e += G) {
         const double v = fabs(val[e]) * dother[idx[e]];
         acc = mode ? acc + v : fmax(acc, v);
     }
-    out[i] = dself[i] * acc;
+    acc = mode ? group_sum<G>(acc) : group_max<G>(acc);
+    if (lane == 0) out[i] = dself[i] * acc;
 }
 __global__ __launch_bounds__(kBlock) void k_scale_apply(int64_t m, double* __restrict__ d, const double* __restrict__ stat) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -565,14 +633,16 @@ __global__ __launch_bounds__(kBlock) void k_scale_apply(int64_t m, double* __res
     if (s > 0.0 && isfinite(s)) d[i] /= sqrt(s);
 }
 // sval_e = dself_i * a_e * dother_idx(e)
+template <int G>
 __global__ __launch_bounds__(kBlock) void k_scale_vals(int64_t m, const int64_t* __restrict__ ptr,
                                                        const int32_t* __restrict__ idx, const double* __restrict__ val,
                                                        const double* __restrict__ dself, const double* __restrict__ dother,
                                                        double* __restrict__ sval) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
     if (i >= m) return;
     const double di = dself[i];
-    for (int64_t e = ptr[i]; e < ptr[i + 1]; ++e) sval[e] = di * val[e] * dother[idx[e]];
+    for (int64_t e = ptr[i] + lane; e < ptr[i + 1]; e += G) sval[e] = di * val[e] * dother[idx[e]];
 }
 
 // scaled problem vectors
@@ -683,12 +753,14 @@ __global__ __launch_bounds__(kBlock) void k_axpy_scaled(int64_t n, const double*
 // ---------------------------------------------------------- CSC mirror build ------
 // key = (col << 32) | row, value = entry index; a radix sort by key orders every column
 // by row index, so the column sums are summed in a fixed order (deterministic).
+template <int G>
 __global__ __launch_bounds__(kBlock) void k_csc_keys(int64_t m, const int64_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ col, uint64_t* __restrict__ keys,
                                                      uint32_t* __restrict__ vals, int64_t* __restrict__ colcount) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
     if (i >= m) return;
-    for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    for (int64_t e = rowptr[i] + lane; e < rowptr[i + 1]; e += G) {
         const uint32_t c = (uint32_t)col[e];
         keys[e] = ((uint64_t)c << 32) | (uint64_t)(uint32_t)i;
         vals[e] = (uint32_t)e;
