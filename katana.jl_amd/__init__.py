@@ -20,7 +20,8 @@ from .solver import (KatanaSolver, KatanaNonlinearModel, KatanaHipSeparator, Non
                      getKatanaModel, getKatanaCuts, getKatanaSols, STATUS_SYMBOLS)
 from .jump_like import Model
 from . import instances
+from .batch import solve_batch
 
 __all__ = ["KatanaSolver", "KatanaNonlinearModel", "KatanaHipSeparator", "NonlinearModel", "getKatanaModel",
            "getKatanaCuts", "getKatanaSols", "NLPDescription", "SeparableNLP", "ExprNLP", "Model", "Expr", "var",
-           "const", "exp", "log", "sqrt", "sin", "cos", "from_sexpr", "instances", "STATUS_SYMBOLS"]
+           "const", "exp", "log", "sqrt", "sin", "cos", "from_sexpr", "instances", "STATUS_SYMBOLS", "solve_batch"]

@@ -94,3 +94,15 @@ def test_full_size_cfg3_properties():
     c = np.zeros(inst.n); c[inst.obj_col] = inst.obj_p0
     assert abs(c @ x - m.getobjval()) <= 1e-9 * max(1, abs(m.getobjval()))   # checksum of the objective
     assert np.max(np.abs(x - inst.xhat)) <= 1e-3
+
+
+def test_batch_throughput_mode_matches_sequential_solves():
+    """BASELINE.json configs[4] (replicas only): independent instances on concurrent streams give the very
+    same results as one-at-a-time solves"""
+    insts = [ktn.instances.make_instance(n=300, m_nl=30, k=8, family="explog", seed=100 + s) for s in range(12)]
+    seq, _ = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts, threads=1)
+    par, _ = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts, threads=4)
+    for a, b, inst in zip(seq, par, insts):
+        assert a["status"] == b["status"] == "Optimal"
+        assert a["objval"] == b["objval"] and a["iters"] == b["iters"] and np.array_equal(a["x"], b["x"])
+        assert abs(a["objval"] - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
