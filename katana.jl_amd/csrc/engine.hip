@@ -191,6 +191,13 @@ struct Engine {
     DBuf<double> dr, dc, statr, statc, ch, lh, uh, loh, hih, xh, yh, x0h, y0h, xth, yth, xbar, pv, pw, box;
     DBuf<double> partials, chkout;
     DBuf<int32_t> d_longrows;
+    DBuf<double> d_sched;               // [0, kMaxChunk+2): plain chunks, [kMaxChunk+2, ...+4): check iterations
+    double* h_sched = nullptr;          // pinned, same two regions
+    static constexpr int kMaxChunk = 512;
+    hipGraph_t lp_graph = nullptr;
+    hipGraphExec_t lp_graph_exec = nullptr;
+    int lp_graph_len = 0;
+    bool use_graph = true;
     int64_t n_long = 0;
     static constexpr int64_t kLongRow = 2048;
     double omega = 1.0;
@@ -229,8 +236,18 @@ struct Engine {
         chkout.resize(kChkQ * 2 + 8, stream);
         d_scal.resize(8, stream);
         d_anynf.resize(2, stream);
+        d_sched.resize(kMaxChunk + 8, stream);
+        KTN_HIP(hipHostMalloc((void**)&h_sched, (kMaxChunk + 8) * sizeof(double), hipHostMallocDefault));
+        use_graph = !prm.profile && std::getenv("KTN_NO_GRAPH") == nullptr;
+    }
+    void drop_graph() {
+        if (lp_graph_exec) { (void)hipGraphExecDestroy(lp_graph_exec); lp_graph_exec = nullptr; }
+        if (lp_graph) { (void)hipGraphDestroy(lp_graph); lp_graph = nullptr; }
+        lp_graph_len = 0;
     }
     ~Engine() {
+        drop_graph();
+        if (h_sched) (void)hipHostFree(h_sched);
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -400,7 +417,10 @@ struct Engine {
     void rebuild_csc();
     void find_long_rows();
     template <bool UPDATE>
-    void launch_y(const SpMat& A, double sigma, double w, double rho, hipEvent_t e0, hipEvent_t e1);
+    void launch_y(const SpMat& A, int step, double rho, hipEvent_t e0, hipEvent_t e1);
+    void launch_x(const SpMat& AT, int step, double rho, bool update, hipEvent_t e0, hipEvent_t e1);
+    double* upload_sched(double tau, double sigma, int64_t k0, int nw, bool check_region);
+    const double* cur_sched = nullptr;
     void compute_scaling(bool identity);
     LpResult lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling = false);
     void pdhg_raw(const double* x0, const double* y0, double eta, double omega_, int64_t iters, double* x_out,
@@ -788,14 +808,36 @@ void Engine::find_long_rows() {
 
 // y-step over all rows: G lanes per row for ordinary rows, a workgroup per row for the long ones
 template <bool UPDATE>
-void Engine::launch_y(const SpMat& A, double sigma, double w, double rho, hipEvent_t e0, hipEvent_t e1) {
+void Engine::launch_y(const SpMat& A, int step, double rho, hipEvent_t e0, hipEvent_t e1) {
     const int64_t m = M;
     const int64_t thr = n_long > 0 ? kLongRow : (int64_t)1 << 62;
-    if (e0) LAUNCH_GB_EV(grp_rows, k_pdhg_y, UPDATE, m, stream, e0, e1, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, rho, thr);
-    else LAUNCH_GB(grp_rows, k_pdhg_y, UPDATE, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, sigma, w, rho, thr);
+    if (e0) LAUNCH_GB_EV(grp_rows, k_pdhg_y, UPDATE, m, stream, e0, e1, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, cur_sched, step, rho, thr);
+    else LAUNCH_GB(grp_rows, k_pdhg_y, UPDATE, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, cur_sched, step, rho, thr);
     if (n_long > 0)
         hipLaunchKernelGGL((k_pdhg_y_long<UPDATE>), dim3((unsigned)n_long), dim3(kLongBlock), 0, stream, d_longrows.p, A, xbar.p, yh.p,
-                           y0h.p, yth.p, loh.p, hih.p, sigma, w, rho);
+                           y0h.p, yth.p, loh.p, hih.p, cur_sched, step, rho);
+}
+void Engine::launch_x(const SpMat& AT, int step, double rho, bool update, hipEvent_t e0, hipEvent_t e1) {
+    const int64_t n = n_lp;
+    if (update) {
+        if (e0) LAUNCH_GB_EV(grp_cols, k_pdhg_x, true, n, stream, e0, e1, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, cur_sched, step, rho);
+        else LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, cur_sched, step, rho);
+    } else {
+        LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, cur_sched, step, rho);
+    }
+}
+// sched = [tau, sigma, w_{k0}, w_{k0+1}, ...]: written to pinned memory and copied stream-ordered.
+// Plain chunks and check iterations use SEPARATE regions: a chunk is launched without a host
+// synchronisation, so the check that follows must not overwrite the pinned words its copy still reads
+// (between two uses of the same region there is always the check's synchronisation).
+double* Engine::upload_sched(double tau, double sigma, int64_t k0, int nw, bool check_region) {
+    const size_t off = check_region ? (size_t)kMaxChunk + 2 : 0;
+    double* h = h_sched + off;
+    h[0] = tau;
+    h[1] = sigma;
+    for (int j = 0; j < nw; ++j) h[2 + j] = (double)(k0 + j + 1) / (double)(k0 + j + 2);
+    KTN_HIP(hipMemcpyAsync(d_sched.p + off, h, (size_t)(2 + nw) * sizeof(double), hipMemcpyHostToDevice, stream));
+    return d_sched.p + off;
 }
 
 LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling) {
@@ -866,28 +908,57 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
     R.status = KTN_STATUS_USERLIMIT;
     const int64_t max_it = prm.lp_max_iter;
     const int chk = std::max(1, prm.lp_check_every);
+    drop_graph();      // pointers, sizes and group widths of this LP differ from the last one
+    const int plain_len = std::min(chk - 1, (int)kMaxChunk);
+    static const int first_chunk = std::getenv("KTN_FIRST_CHUNK") ? std::atoi(std::getenv("KTN_FIRST_CHUNK")) : 31;
+    bool plain_next = false;
     while (it < max_it) {
         const double tau = eta / om, sigma = eta * om;
-        const bool check = (it % chk == 0) || k == 0;
-        if (!check) {
-            const double w = (double)(k + 1) / (double)(k + 2);
+        if (plain_next) {
+            // ---- a chunk of plain (update) iterations between two checks
+            plain_next = false;
+            // the first chunk after a restart is shorter: the restarted iteration moves fastest there and an
+            // early check catches the next restart / termination sooner
+            const int want = (k <= 1 && first_chunk > 0) ? std::min(first_chunk, plain_len) : plain_len;
+            const int np = (int)std::min<int64_t>(want, max_it - it);
+            if (np <= 0) continue;
+            cur_sched = upload_sched(tau, sigma, k, np, false);
             if (prm.profile) {
-                const size_t e0 = ev_get(), e1 = ev_get(), e2 = ev_get(), e3 = ev_get();
-                LAUNCH_GB_EV(grp_cols, k_pdhg_x, true, n, stream, ev_pool[e0], ev_pool[e1], n, AT, yh.p, xh.p, x0h.p, xth.p,
-                             xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
-                launch_y<true>(A, sigma, w, rho, ev_pool[e2], ev_pool[e3]);
-                ev_recs.push_back({0, e0, e1, kx_bytes});
-                if (m > 0) ev_recs.push_back({1, e2, e3, ky_bytes});
+                for (int j = 0; j < np; ++j) {
+                    const size_t e0 = ev_get(), e1 = ev_get(), e2 = ev_get(), e3 = ev_get();
+                    launch_x(AT, j, rho, true, ev_pool[e0], ev_pool[e1]);
+                    launch_y<true>(A, j, rho, ev_pool[e2], ev_pool[e3]);
+                    ev_recs.push_back({0, e0, e1, kx_bytes});
+                    if (m > 0) ev_recs.push_back({1, e2, e3, ky_bytes});
+                }
+            } else if (use_graph && np == plain_len && np >= 8) {
+                if (!lp_graph_exec) {
+                    // capture the chunk once per LP solve; ThreadLocal so that other host threads (batch mode)
+                    // may keep calling hipMalloc / hipMemcpy on their own streams meanwhile
+                    KTN_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                    for (int j = 0; j < np; ++j) {
+                        launch_x(AT, j, rho, true, nullptr, nullptr);
+                        launch_y<true>(A, j, rho, nullptr, nullptr);
+                    }
+                    KTN_HIP(hipStreamEndCapture(stream, &lp_graph));
+                    KTN_HIP(hipGraphInstantiate(&lp_graph_exec, lp_graph, nullptr, nullptr, 0));
+                    lp_graph_len = np;
+                    stats["lp_graph_captures"] += 1.0;
+                }
+                KTN_HIP(hipGraphLaunch(lp_graph_exec, stream));
             } else {
-                LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
-                launch_y<true>(A, sigma, w, rho, nullptr, nullptr);
+                for (int j = 0; j < np; ++j) {
+                    launch_x(AT, j, rho, true, nullptr, nullptr);
+                    launch_y<true>(A, j, rho, nullptr, nullptr);
+                }
             }
-            ++k; ++it;
+            k += np; it += np;
             continue;
         }
         // ---- check iteration: PDHG step without update, KKT + fixed-point residual
-        LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, 0.0, rho);
-        launch_y<false>(A, sigma, 0.0, rho, nullptr, nullptr);
+        cur_sched = upload_sched(tau, sigma, k, 1, true);
+        launch_x(AT, 0, rho, false, nullptr, nullptr);
+        launch_y<false>(A, 0, rho, nullptr, nullptr);
         hipLaunchKernelGGL(k_chk_rows, dim3(kRedBlocks), dim3(kBlock), 0, stream, m, A, xh.p, xth.p, yh.p, yth.p, y0h.p,
                            loh.p, hih.p, dr.p, d_longrows.p, n_long, (n_long > 0 ? kLongRow : (int64_t)1 << 62), partials.p);
         hipLaunchKernelGGL(k_chk_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, chkout.p);
@@ -981,7 +1052,9 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
         LAUNCH_1(k_halpern, n, stream, n, xh.p, xth.p, x0h.p, w, rho);
         LAUNCH_1(k_halpern, m, stream, m, yh.p, yth.p, y0h.p, w, rho);
         ++k; ++it;
+        plain_next = true;       // (after a restart k == 0 and the next pass is a check again: it needs r0)
     }
+    drop_graph();
     R.iters = it;
     // un-scale the last PDHG point (xt, yt)
     if (mode == 0) {
@@ -1024,10 +1097,15 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
     if (m > 0) KTN_HIP(hipMemcpyAsync(y0h.p, yh.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
     find_long_rows();
     const double tau = eta / omega_, sigma = eta * omega_;
-    for (int64_t k = 0; k < iters; ++k) {
-        const double w = (double)(k + 1) / (double)(k + 2);
-        LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, 1.0);
-        launch_y<true>(A, sigma, w, 1.0, nullptr, nullptr);
+    for (int64_t k = 0; k < iters;) {
+        const int np = (int)std::min<int64_t>(kMaxChunk, iters - k);
+        cur_sched = upload_sched(tau, sigma, k, np, false);
+        for (int j = 0; j < np; ++j) {
+            launch_x(AT, j, 1.0, true, nullptr, nullptr);
+            launch_y<true>(A, j, 1.0, nullptr, nullptr);
+        }
+        sync();
+        k += np;
     }
     check_launch();
     KTN_HIP(hipMemcpyAsync(x_out, xh.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));

@@ -390,7 +390,11 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_x(int64_t n, SpMat AT, const do
                                                    double* __restrict__ x, const double* __restrict__ x0,
                                                    double* __restrict__ xt, double* __restrict__ xbar,
                                                    const double* __restrict__ c, const double* __restrict__ l,
-                                                   const double* __restrict__ u, double tau, double w, double rho) {
+                                                   const double* __restrict__ u, const double* __restrict__ sched,
+                                                   int step, double rho) {
+    // step sizes and Halpern weights live in device memory (sched = [tau, sigma, w_0, w_1, ...]) so that
+    // a captured hipGraph of a whole chunk of iterations can be replayed with new values
+    const double tau = sched[0], w = sched[2 + step];
     const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     if (j >= n) return;
@@ -413,8 +417,9 @@ template <int G, bool UPDATE>
 __global__ __launch_bounds__(kBlock) void k_pdhg_y(int64_t m, SpMat A, const double* __restrict__ xbar,
                                                    double* __restrict__ y, const double* __restrict__ y0,
                                                    double* __restrict__ yt, const double* __restrict__ lo,
-                                                   const double* __restrict__ hi, double sigma, double w, double rho,
-                                                   int64_t long_thresh) {
+                                                   const double* __restrict__ hi, const double* __restrict__ sched,
+                                                   int step, double rho, int64_t long_thresh) {
+    const double sigma = sched[1], w = sched[2 + step];
     const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     if (i >= m) return;
@@ -440,7 +445,8 @@ __global__ __launch_bounds__(kLongBlock) void k_pdhg_y_long(const int32_t* __res
                                                         const double* __restrict__ xbar, double* __restrict__ y,
                                                         const double* __restrict__ y0, double* __restrict__ yt,
                                                         const double* __restrict__ lo, const double* __restrict__ hi,
-                                                        double sigma, double w, double rho) {
+                                                        const double* __restrict__ sched, int step, double rho) {
+    const double sigma = sched[1], w = sched[2 + step];
     const int64_t i = rows[blockIdx.x];
     const int64_t beg = A.ptr[i], end = A.ptr[i + 1];
     double acc = 0.0;
