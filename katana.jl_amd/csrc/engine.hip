@@ -888,7 +888,7 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
     if (!(smax > 0.0)) smax = fro;
     const double eta_safe = 0.998 / std::max(identity_scaling ? fro : std::min(1.0, fro), 1e-12);
     double eta = std::max(0.998 / std::max(smax, 1e-12), eta_safe);
-    int stall = 0, flat_rows = 0, consolidations = 0;
+    int stall = 0, flat_rows = 0, consolidations = 0, infeas_hits = 0;
     double r_last_check = 0.0;
     const double nc2 = dev_dot(n, ch.p, ch.p);
     const double nb2 = (m > 0) ? dev_finite_sq(m, loh.p) + dev_finite_sq(m, hih.p) : 0.0;
@@ -987,6 +987,19 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
             R.status = done ? KTN_STATUS_OPTIMAL : KTN_STATUS_ERROR;
             ++it;
             break;
+        }
+        // primal infeasibility: yt is a Farkas certificate when the dual objective of the c = 0 problem is
+        // positive (weak duality makes it <= 0 for every sign-valid y of a feasible LP).  Two checks in a row.
+        if (mode == 0 && m > 0) {
+            const double farkas = dobj_rows + q[kChkQ + 10];
+            const double mag = q[10] + q[kChkQ + 11] + 1e-300;
+            const bool cert = farkas > 1e-6 * mag && q[kChkQ + 14] <= 1e-9 * (1.0 + std::sqrt(yt2)) && pviol > tol_p;
+            infeas_hits = cert ? infeas_hits + 1 : 0;
+            if (infeas_hits >= 2 && it >= 2 * chk) {
+                R.status = KTN_STATUS_INFEASIBLE;
+                ++it;
+                break;
+            }
         }
         bool restart = k > 0 && (r <= 0.2 * r0 || (r <= 0.8 * r0 && r > r_prev) || (double)k >= 0.36 * (double)(it + 1));
         // step-size safeguard: a fixed-point residual that no longer moves (or a negative M-norm) while

@@ -535,8 +535,8 @@ __device__ __forceinline__ void chk_row_accumulate(ChkAcc& a, int64_t i, double 
     const double ytv = yt[i], dy = ytv - y[i];
     a.s[0] += dy * (axt - axk);
     a.s[1] += dy * dy;
-    if (ytv > 0.0) a.s[2] += lo[i] * ytv;        // lo finite whenever yt > 0 (prox keeps y <= 0 otherwise)
-    else if (ytv < 0.0) a.s[2] += hi[i] * ytv;
+    if (ytv > 0.0) { a.s[2] += lo[i] * ytv; a.s[10] += fabs(lo[i] * ytv); }   // lo finite whenever yt > 0
+    else if (ytv < 0.0) { a.s[2] += hi[i] * ytv; a.s[10] += fabs(hi[i] * ytv); }
     const double d0 = ytv - y0[i];
     a.s[3] += d0 * d0;
     a.s[4] += ytv * ytv;
@@ -587,6 +587,7 @@ __global__ __launch_bounds__(kBlock) void k_chk_rows(int64_t m, SpMat A, const d
 }
 
 //  s5 sum dx^2  s6 primal objective  s7 dual objective (bounds)  s8 sum (xt-x0)^2  s9 sum xt^2
+//  s10 Farkas value (bounds part)  s11 its absolute terms  m14 max reduced cost of the c=0 problem on an infinite bound
 //  m13 max unscaled dual residual (reduced cost not absorbable by a finite bound)
 __global__ __launch_bounds__(kBlock) void k_chk_cols(int64_t n, SpMat AT, const double* __restrict__ x,
                                                      const double* __restrict__ xt, const double* __restrict__ x0,
@@ -608,6 +609,10 @@ __global__ __launch_bounds__(kBlock) void k_chk_cols(int64_t n, SpMat AT, const 
         a.s[8] += d0 * d0;
         a.s[9] += xtv * xtv;
         a.s[13] = fmax(a.s[13], bad / dc[j]);
+        // Farkas value of yt: the dual objective with c = 0 (positive <=> the rows + bounds are infeasible)
+        const double r0 = -aty;
+        if (r0 > 0.0) { if (isfinite(l[j])) { a.s[10] += l[j] * r0; a.s[11] += fabs(l[j] * r0); } else a.s[14] = fmax(a.s[14], r0); }
+        else if (r0 < 0.0) { if (isfinite(u[j])) { a.s[10] += u[j] * r0; a.s[11] += fabs(u[j] * r0); } else a.s[14] = fmax(a.s[14], -r0); }
     }
     chk_block_store(a, partials);
 }

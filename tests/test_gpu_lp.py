@@ -88,3 +88,22 @@ def test_lp_with_no_rows_goes_to_the_bounds():
     x = m.getsolution()
     assert x[0] == -1.0 and x[1] == 3.0 and abs(m.getobjval() - (-1.0 - 6.0 + 0.5)) < 1e-12
     assert m.numiters() == 1 and m.numcuts() == 0
+
+
+def test_infeasible_lp_status_is_passed_through():
+    """LP status other than :Optimal is returned as is (src/model.jl:261-263); the GPU LP certifies primal
+    infeasibility with a Farkas multiplier"""
+    x, y = ktn.var(0), ktn.var(1)
+    M = ktn.Model(solver=ktn.KatanaSolver(log_level=0))
+    M.variable(-5, 5); M.variable(-5, 5)
+    M.objective("Min", x + y)
+    M.constraint(x + y >= 3.0)
+    M.constraint(x + 2 * y <= 1.0)
+    M.constraint(x - 0 * y <= 0.5)          # x <= 0.5  => y >= 2.5 => x + 2y >= 5.5 > 1: empty
+    M.constraint(x ** 2 + y ** 2 <= 100.0)
+    assert M.solve() == "Infeasible"
+    # and the oracle's LP says the same
+    from oracle.lp import LinearModel
+    lm = LinearModel(); lm.add_variables([-5, -5], [5, 5]); lm.set_objective("Min", [0, 1], [1.0, 1.0])
+    lm.add_rows([0, 2, 4, 5], [0, 1, 0, 1, 0], [1, 1, 1, 2, 1], [3, -np.inf, -np.inf], [np.inf, 1, 0.5])
+    assert lm.solve() == "Infeasible"
