@@ -64,7 +64,8 @@ def exchange_cuts(dist, block, device="cpu"):
     import torch
     rowptr, col, val, lo, hi = block
     nrows, nnz = len(lo), len(col)
-    if dist is None or dist.get_world_size() == 1:
+    import os
+    if dist is None or (dist.get_world_size() == 1 and not os.environ.get("KTN_FORCE_COLLECTIVE")):
         return [block]
     world = dist.get_world_size()
     counts = torch.tensor([nrows, nnz], dtype=torch.int64, device=device)
@@ -151,7 +152,8 @@ class ShardedKatanaModel:
         return self.allsat or self.iter >= self.p["iter_cap"]
 
     def _allreduce_max(self, a, b):
-        if self.dist is None or self.world == 1:
+        import os
+        if self.dist is None or (self.world == 1 and not os.environ.get("KTN_FORCE_COLLECTIVE")):
             return a, b
         import torch
         t = torch.tensor([a, b], dtype=torch.float64, device=self.exchange_device)
