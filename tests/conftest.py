@@ -11,6 +11,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the C-ABI library is a build product (git-ignored): build it when the tree is fresh
+    lib = os.path.join(ROOT, "katana.jl_amd", "libkatana_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "katana.jl_amd", "csrc")], check=True)
 
 
 @pytest.fixture(scope="session")
