@@ -100,6 +100,14 @@ typedef struct {
     int32_t lp_dual_inherit;/* 1       new cut of NL row i inherits the dual of its
                                        previous cut (warm start)                    */
     int32_t profile;        /* 0       per-launch hipEvent timing of the hot kernels */
+    /* cut-pool management (the reference never removes cuts, src/model.jl:215) */
+    int32_t purge_age;      /* 2       drop a cut that had no multiplier and was slack at x* in this many
+                                       consecutive LP solves; 0 = keep every cut like the reference      */
+    double  purge_margin;   /* 1e-3    ... slack by more than purge_margin * max(1, |row bound|)          */
+    double  purge_min_frac; /* 0.05    compact only when at least this fraction of the LP rows goes      */
+    int64_t purge_min_rows; /* 50000   ... and only once the pool holds this many cuts: on small smooth
+                                       problems (optimum on a curved face, e.g. test/2d.jl 107_01) dropping
+                                       idle cuts makes Kelley's method cycle, so small pools are never purged */
 } ktn_params;
 
 /* The device-evaluable statement of the NLP: replaces the

@@ -23,7 +23,8 @@ class KtnParams(C.Structure):
                 ("obj_eps", c_f64), ("vis_data", c_i32), ("device", c_i32), ("lp_max_iter", c_i32),
                 ("lp_check_every", c_i32), ("lp_ruiz_iters", c_i32), ("lp_tol_scale", c_f64),
                 ("lp_tol_floor", c_f64), ("lp_tol_cap", c_f64), ("lp_gap_floor", c_f64), ("lp_gap_cap", c_f64),
-                ("lp_dual_inherit", c_i32), ("profile", c_i32)]
+                ("lp_dual_inherit", c_i32), ("profile", c_i32), ("purge_age", c_i32), ("purge_margin", c_f64),
+                ("purge_min_frac", c_f64), ("purge_min_rows", c_i64)]
 
 
 class KtnNlpDesc(C.Structure):

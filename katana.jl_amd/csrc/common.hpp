@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -67,6 +68,11 @@ struct DBuf {
     void resize(size_t want, hipStream_t s) {
         reserve(want, s);
         n = want;
+    }
+    void swap(DBuf& o) {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+        std::swap(cap, o.cap);
     }
     void zero(hipStream_t s) {
         if (n) KTN_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));

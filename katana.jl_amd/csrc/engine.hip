@@ -169,6 +169,10 @@ struct Engine {
     DBuf<int32_t> d_nonfin, d_violslots, d_anynf;
     DBuf<int64_t> d_flag, d_cnt, d_rank, d_cntscan, d_lastcut, d_cutprev;
     DBuf<double> d_ones;
+    DBuf<int32_t> d_age, d_age2;
+    DBuf<int64_t> d_keep, d_keepnnz, d_newidx, d_newptr, d_cutprev2, lp_rowptr2;
+    DBuf<int32_t> lp_col2;
+    DBuf<double> lp_val2, lp_lo2, lp_hi2, lp_y2;
     DBuf<char> d_scantmp;
     bool have_precompute = false;
 
@@ -394,6 +398,8 @@ struct Engine {
             lp_hi.resize((size_t)(M + V), stream);
             lp_y.resize((size_t)(M + V), stream);
             d_cutprev.resize((size_t)(M + V), stream);
+            d_age.resize((size_t)(M + V), stream);
+            KTN_HIP(hipMemsetAsync(d_age.p + M, 0, (size_t)V * sizeof(int32_t), stream));
             lp_col.resize((size_t)(NNZ + nnzV), stream);
             lp_val.resize((size_t)(NNZ + nnzV), stream);
             d_violslots.resize((size_t)V, stream);
@@ -415,6 +421,7 @@ struct Engine {
 
     // ================================================================ LP ============
     void rebuild_csc();
+    void purge_cuts();
     void find_long_rows();
     template <bool UPDATE>
     void launch_y(const SpMat& A, int step, double rho, hipEvent_t e0, hipEvent_t e1);
@@ -732,6 +739,8 @@ void Engine::reset() {
     lp_y.zero(stream); lp_x.zero(stream);
     std::vector<int64_t> neg1((size_t)std::max<int64_t>(m_ext, 1), -1);
     d_lastcut.upload(neg1, stream);
+    d_age.resize((size_t)std::max<int64_t>(M, 1), stream);
+    d_age.zero(stream);
     lp_dirty = true; have_omega = false; have_precompute = false; sharded_rows = false;
     status = KTN_STATUS_NONE; lp_status = KTN_STATUS_OPTIMAL;
     iter = 0; soltime = 0.0; objval = std::numeric_limits<double>::quiet_NaN();
@@ -767,6 +776,45 @@ void Engine::rebuild_csc() {
         check_launch();
     }
     lp_dirty = false;
+}
+
+// Cut-pool management after an LP solve (k_purge_mark / k_purge_copy / k_purge_relink).
+void Engine::purge_cuts() {
+    const int64_t m = M;
+    d_age.resize((size_t)m, stream);
+    d_keep.resize((size_t)m, stream); d_keepnnz.resize((size_t)m, stream);
+    d_newidx.resize((size_t)m, stream); d_newptr.resize((size_t)m, stream);
+    LAUNCH_1(k_purge_mark, m, stream, M_base, m, lp_rowptr.p, lp_col.p, lp_val.p, lp_x.p, lp_lo.p, lp_hi.p, lp_y.p, d_age.p,
+             prm.purge_margin, (int)prm.purge_age, d_keep.p, d_keepnnz.p);
+    check_launch();
+    exclusive_scan(d_keep.p, d_newidx.p, (size_t)m);
+    exclusive_scan(d_keepnnz.p, d_newptr.p, (size_t)m);
+    int64_t t[4];
+    KTN_HIP(hipMemcpyAsync(&t[0], d_keep.p + (m - 1), 8, hipMemcpyDeviceToHost, stream));
+    KTN_HIP(hipMemcpyAsync(&t[1], d_newidx.p + (m - 1), 8, hipMemcpyDeviceToHost, stream));
+    KTN_HIP(hipMemcpyAsync(&t[2], d_keepnnz.p + (m - 1), 8, hipMemcpyDeviceToHost, stream));
+    KTN_HIP(hipMemcpyAsync(&t[3], d_newptr.p + (m - 1), 8, hipMemcpyDeviceToHost, stream));
+    sync();
+    const int64_t m_new = t[0] + t[1], nnz_new = t[2] + t[3];
+    if (m - m_new < (int64_t)(prm.purge_min_frac * (double)m) || m_new == m) return;
+    lp_rowptr2.resize((size_t)m_new + 1, stream); lp_col2.resize((size_t)nnz_new + 1, stream);
+    lp_val2.resize((size_t)nnz_new + 1, stream); lp_lo2.resize((size_t)m_new, stream); lp_hi2.resize((size_t)m_new, stream);
+    lp_y2.resize((size_t)m_new, stream); d_age2.resize((size_t)m_new, stream); d_cutprev2.resize((size_t)m_new, stream);
+    LpRows Old = lp_view();
+    LpRows New{lp_rowptr2.p, lp_col2.p, lp_val2.p, lp_lo2.p, lp_hi2.p, lp_y2.p};
+    LAUNCH_1(k_purge_copy, m, stream, m, d_keep.p, d_newidx.p, d_newptr.p, Old, d_age.p, New, d_age2.p);
+    KTN_HIP(hipMemcpyAsync(lp_rowptr2.p + m_new, &nnz_new, 8, hipMemcpyHostToDevice, stream));
+    LAUNCH_1(k_purge_relink, m_nl, stream, m_nl, d_lastcut.p, d_cutprev.p, d_keep.p, d_newidx.p, d_cutprev2.p);
+    check_launch();
+    sync();
+    lp_rowptr.swap(lp_rowptr2); lp_col.swap(lp_col2); lp_val.swap(lp_val2); lp_lo.swap(lp_lo2); lp_hi.swap(lp_hi2);
+    lp_y.swap(lp_y2); d_age.swap(d_age2); d_cutprev.swap(d_cutprev2);
+    lp_rowptr.n = (size_t)m_new + 1; lp_col.n = lp_val.n = (size_t)nnz_new;
+    lp_lo.n = lp_hi.n = lp_y.n = d_age.n = d_cutprev.n = (size_t)m_new;
+    stats["purged_rows"] += (double)(m - m_new);
+    stats["purges"] += 1.0;
+    M = m_new; NNZ = nnz_new;
+    lp_dirty = true;
 }
 
 void Engine::compute_scaling(bool identity) {
@@ -1192,6 +1240,7 @@ void Engine::step(int32_t* done) {
     lp_status = R.status;
     if (R.status != KTN_STATUS_OPTIMAL) { status = R.status; return; }   // model.jl:261-263
     if (prm.vis_data) lp_sols.push_back(lp_x.to_host(stream));          // model.jl:267
+    if (prm.purge_age > 0 && !prm.vis_data && !sharded_rows && M - M_base >= std::max<int64_t>(prm.purge_min_rows, 1)) purge_cuts();
     int64_t nviol = 0;
     double mv = 0.0;
     bool nonfin = false;
@@ -1258,6 +1307,7 @@ void ktn_default_params(ktn_params* p) {
     p->lp_max_iter = 2000000; p->lp_check_every = 64; p->lp_ruiz_iters = 10;
     p->lp_tol_scale = 0.1; p->lp_tol_floor = 0.3; p->lp_tol_cap = 0.1; p->lp_gap_floor = 1e-7; p->lp_gap_cap = 1e-2;
     p->lp_dual_inherit = 1; p->profile = 0;
+    p->purge_age = 2; p->purge_margin = 1e-3; p->purge_min_frac = 0.05; p->purge_min_rows = 50000;
 }
 
 int ktn_create(const ktn_params* p, ktn_handle* out) {

@@ -348,6 +348,63 @@ __global__ __launch_bounds__(kBlock) void k_consolidate(int64_t m_nl, const int6
     if (mass_l != 0.0) { y[best_l] += mass_l / dr[best_l]; atomicAdd(moved, 1); }
 }
 
+// ------------------------------------------------------------------ cut-pool management ----
+// (the reference never removes cuts, src/model.jl:215 TODO.)  A cut that carries
+// no multiplier and is slack at x* for `max_age` consecutive LP solves is dropped: every cut is a valid
+// inequality of the convex feasible set, so dropping one keeps the LP an outer approximation, and the sweep
+// regenerates it should its row become violated again.
+__global__ __launch_bounds__(kBlock) void k_purge_mark(int64_t m_base, int64_t m, const int64_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                       const double* __restrict__ x, const double* __restrict__ lo,
+                                                       const double* __restrict__ hi, const double* __restrict__ y,
+                                                       int32_t* __restrict__ age, double margin, int max_age,
+                                                       int64_t* __restrict__ keep, int64_t* __restrict__ keepnnz) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= m) return;
+    const int64_t len = rowptr[r + 1] - rowptr[r];
+    bool k = true;
+    if (r >= m_base) {
+        double ax = 0.0;
+        for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) ax += val[e] * x[col[e]];
+        double slack = __builtin_inf(), scale = 1.0;
+        if (isfinite(hi[r])) { slack = fmin(slack, hi[r] - ax); scale = fmax(scale, fabs(hi[r])); }
+        if (isfinite(lo[r])) { slack = fmin(slack, ax - lo[r]); scale = fmax(scale, fabs(lo[r])); }
+        const bool idle = (y[r] == 0.0) && (slack > margin * scale);
+        const int a = idle ? age[r] + 1 : 0;
+        age[r] = a;
+        k = a < max_age;
+    }
+    keep[r] = k ? 1 : 0;
+    keepnnz[r] = k ? len : 0;
+}
+__global__ __launch_bounds__(kBlock) void k_purge_copy(int64_t m, const int64_t* __restrict__ keep, const int64_t* __restrict__ newidx,
+                                                       const int64_t* __restrict__ newptr, LpRows Old, const int32_t* __restrict__ age_old,
+                                                       LpRows New, int32_t* __restrict__ age_new) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= m || !keep[r]) return;
+    const int64_t nr = newidx[r], dst = newptr[r], src = Old.rowptr[r], len = Old.rowptr[r + 1] - src;
+    New.rowptr[nr] = dst;
+    for (int64_t e = 0; e < len; ++e) { New.col[dst + e] = Old.col[src + e]; New.val[dst + e] = Old.val[src + e]; }
+    New.lo[nr] = Old.lo[r]; New.hi[nr] = Old.hi[r]; New.y[nr] = Old.y[r];
+    age_new[nr] = age_old[r];
+}
+// re-thread the per-NL-row cut lists (k_consolidate) through the kept rows
+__global__ __launch_bounds__(kBlock) void k_purge_relink(int64_t m_nl, int64_t* __restrict__ last_cut,
+                                                         const int64_t* __restrict__ prev_old, const int64_t* __restrict__ keep,
+                                                         const int64_t* __restrict__ newidx, int64_t* __restrict__ prev_new) {
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= m_nl) return;
+    int64_t head = -1, tail = -1;
+    for (int64_t r = last_cut[s]; r >= 0; r = prev_old[r]) {
+        if (!keep[r]) continue;
+        const int64_t nr = newidx[r];
+        if (head < 0) head = nr; else prev_new[tail] = nr;
+        tail = nr;
+    }
+    if (tail >= 0) prev_new[tail] = -1;
+    last_cut[s] = head;
+}
+
 // gencut + round_coefs + row append: G lanes per violated row.
 template <int G>
 __global__ __launch_bounds__(kBlock) void k_emit(NlpDev P, const int32_t* __restrict__ nl_rows,

@@ -134,7 +134,7 @@ def test_two_rank_sharded_solve_matches_single_gpu():
     out = mp.Manager().dict()
     mp.spawn(_worker_gpu, args=(world, _free_port(), out), nprocs=world, join=True)
     inst = ktn.instances.make_instance(n=4000, m_nl=400, k=16, family="explog", seed=21)
-    single = hip_load_instance(ktn, inst, lp_dual_inherit=0)
+    single = hip_load_instance(ktn, inst, lp_dual_inherit=0, purge_age=0)
     assert single.optimize() == "Optimal"
     (s0, o0, it0, c0, x0), (s1, o1, it1, c1, x1) = out[0], out[1]
     assert s0 == s1 == "Optimal"
@@ -153,6 +153,6 @@ def test_sharded_model_world1_equals_engine_loop():
     inst = ktn.instances.make_instance(n=2000, m_nl=200, k=16, family="quad", seed=5)
     a = ShardedKatanaModel(ktn.KatanaSolver(log_level=0), inst, 0, 1, None)
     assert a.optimize() == "Optimal"
-    b = hip_load_instance(ktn, inst, lp_dual_inherit=0)
+    b = hip_load_instance(ktn, inst, lp_dual_inherit=0, purge_age=0)
     assert b.optimize() == "Optimal"
     assert a.getobjval() == b.getobjval() and a.numiters() == b.numiters() and a.numcuts() == b.numcuts()

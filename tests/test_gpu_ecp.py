@@ -106,3 +106,17 @@ def test_batch_throughput_mode_matches_sequential_solves():
         assert a["status"] == b["status"] == "Optimal"
         assert a["objval"] == b["objval"] and a["iters"] == b["iters"] and np.array_equal(a["x"], b["x"])
         assert abs(a["objval"] - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+
+
+def test_cut_pool_purging_keeps_the_answer():
+    """idle cuts are dropped once the pool is large; objective, feasibility and status
+    are those of the never-purging run (the reference's behaviour, src/model.jl:215)"""
+    inst = ktn.instances.make_instance(n=3000, m_nl=3000, k=16, family="explog", seed=4, active_frac=0.02)
+    keep = hip_load_instance(ktn, inst, purge_age=0)
+    assert keep.optimize() == "Optimal"
+    purge = hip_load_instance(ktn, inst, purge_age=2, purge_min_rows=500)
+    assert purge.optimize() == "Optimal"
+    assert purge.stat("purged_rows") > 0 and purge.lp_num_rows() < keep.lp_num_rows()
+    assert purge.numcuts() >= purge.lp_num_rows()                       # numcuts stays cumulative (model.jl:333)
+    assert abs(purge.getobjval() - keep.getobjval()) <= OBJ_RTOL * max(1.0, abs(keep.getobjval()))
+    assert max_nl_violation(inst, purge.getsolution()) <= 1e-6 * (1 + 1e-6)
