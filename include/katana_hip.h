@@ -105,7 +105,7 @@ typedef struct {
                                        consecutive LP solves; 0 = keep every cut like the reference      */
     double  purge_margin;   /* 1e-3    ... slack by more than purge_margin * max(1, |row bound|)          */
     double  purge_min_frac; /* 0.05    compact only when at least this fraction of the LP rows goes      */
-    int64_t purge_min_rows; /* 50000   ... and only once the pool holds this many cuts: on small smooth
+    int64_t purge_min_rows; /* 2000    ... and only once the pool holds this many cuts: on small smooth
                                        problems (optimum on a curved face, e.g. test/2d.jl 107_01) dropping
                                        idle cuts makes Kelley's method cycle, so small pools are never purged */
 } ktn_params;
