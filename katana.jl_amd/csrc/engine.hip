@@ -907,6 +907,8 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
     const double avg_r = m ? (double)NNZ / (double)m : 1.0, avg_c = n ? (double)NNZ / (double)n : 1.0;
     grp_rows = pick_group(avg_r);
     grp_cols = pick_group(avg_c);
+    if (const char* g = std::getenv("KTN_GRP_ROWS")) grp_rows = std::atoi(g);
+    if (const char* g = std::getenv("KTN_GRP_COLS")) grp_cols = std::atoi(g);
     SpMat A{lp_rowptr.p, lp_col.p, r_sval.p};
     SpMat AT{c_ptr.p, c_row.p, c_sval.p};
     find_long_rows();

@@ -456,14 +456,16 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_x(int64_t n, SpMat AT, const do
     const int lane = threadIdx.x & (G - 1);
     if (j >= n) return;
     const int64_t beg = AT.ptr[j], end = AT.ptr[j + 1];
+    // the per-column scalars are requested up front by every lane of the group (same address: one
+    // transaction), so their latency overlaps the gather chain instead of following the reduction
+    const double xv = x[j], cj = c[j], lj = l[j], uj = u[j], x0j = UPDATE ? x0[j] : 0.0;
     double acc = 0.0;
     for (int64_t e = beg + lane; e < end; e += G) acc += AT.val[e] * y[AT.idx[e]];
     acc = group_sum<G>(acc);
     if (lane == 0) {
-        const double xv = x[j];
-        const double xtv = clampd(xv - tau * (c[j] - acc), l[j], u[j]);
+        const double xtv = clampd(xv - tau * (cj - acc), lj, uj);
         xbar[j] = 2.0 * xtv - xv;
-        if (UPDATE) x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0[j];
+        if (UPDATE) x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0j;
         else xt[j] = xtv;
     }
 }
@@ -482,14 +484,14 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_y(int64_t m, SpMat A, const dou
     if (i >= m) return;
     const int64_t beg = A.ptr[i], end = A.ptr[i + 1];
     if (end - beg > long_thresh) return;          // served by k_pdhg_y_long (a workgroup per row)
+    const double yv = y[i], loi = lo[i], hii = hi[i], y0i = UPDATE ? y0[i] : 0.0;
     double acc = 0.0;
     for (int64_t e = beg + lane; e < end; e += G) acc += A.val[e] * xbar[A.idx[e]];
     acc = group_sum<G>(acc);
     if (lane == 0) {
-        const double yv = y[i];
         const double v = yv - sigma * acc;
-        const double ytv = v + sigma * clampd(-v / sigma, lo[i], hi[i]);
-        if (UPDATE) y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0[i];
+        const double ytv = v + sigma * clampd(-v / sigma, loi, hii);
+        if (UPDATE) y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0i;
         else yt[i] = ytv;
     }
 }
