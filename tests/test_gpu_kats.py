@@ -58,3 +58,48 @@ def test_visdata_feature_records_lp_iterates_and_cut_table():
     assert len(sols) == M.internal_model.numiters() and len(sols[0]) == 2
     table = ktn.getKatanaCuts(M)                       # src/util.jl:16-34
     assert table.shape == (M.internal_model.numcuts(), 2 + 2) and np.all(table[:, -1] == -1)
+
+
+def test_equality_range_and_fixed_variables():
+    """linear rows with two finite sides (range / equality) and fixed variables go straight through the
+    tangent-at-the-origin pass (src/model.jl:115-118) and the LP"""
+    x, y, z = ktn.var(0), ktn.var(1), ktn.var(2)
+    M = ktn.Model(solver=ktn.KatanaSolver(log_level=0))
+    M.variable(-3, 3); M.variable(-3, 3); M.variable(0.25, 0.25)          # z fixed
+    M.objective("Min", -x - 2 * y + z)
+    M.constraint((x + y, 1.0, 1.0))                                        # equality  x + y == 1
+    M.constraint((x - y, -2.0, 0.5))                                       # range
+    M.constraint(x ** 2 + y ** 2 <= 4.0)
+    assert M.solve() == "Optimal"
+    xs = M.getvalue()
+    # optimum of min -x-2y on {x+y=1, -2<=x-y<=.5, circle radius 2}: push y up: x-y=-2 -> x=-.5,y=1.5 (inside circle: 2.5<4)
+    assert abs(xs[0] + 0.5) < 1e-5 and abs(xs[1] - 1.5) < 1e-5 and xs[2] == 0.25
+    assert abs(M.getobjectivevalue() - (0.5 - 3.0 + 0.25)) < 1e-6
+
+
+def test_truly_unbounded_problem_returns_unbounded():
+    """an LP that stays unbounded after num_var bounding rounds is reported :Unbounded (src/model.jl:244-247)"""
+    x, y = ktn.var(0), ktn.var(1)
+    M = ktn.Model(solver=ktn.KatanaSolver(log_level=0))
+    M.variable(); M.variable()
+    M.objective("Min", x)
+    M.constraint(y ** 2 <= 1.0)                                            # does not bound x
+    assert M.solve() == "Unbounded"
+    # the oracle agrees
+    from helpers import oracle_solve_kat
+    om = oracle_solve_kat({"vars": [{"lb": -np.inf, "ub": np.inf}] * 2, "objective": ["var", 0], "objective_linear": True,
+                           "sense": "Min", "constraints": [{"expr": ["-", ["^", ["var", 1], 2.0], 1.0], "lb": -np.inf,
+                                                            "ub": 0.0, "linear": False}]})
+    assert om.getstatus() == "Unbounded"
+
+
+def test_max_sense_with_nonlinear_objective():
+    """Max of a concave objective: epigraph bounds (0, Inf) (src/model.jl:144)"""
+    x, y = ktn.var(0), ktn.var(1)
+    M = ktn.Model(solver=ktn.KatanaSolver(log_level=0))
+    M.variable(-2, 2); M.variable(-2, 2)
+    M.objective("Max", -((x - 1.0) ** 2) - (y - 1.0) ** 2)
+    M.constraint(x ** 2 + y ** 2 <= 1.0)
+    assert M.solve() == "Optimal"
+    assert abs(M.getobjectivevalue() + 0.17157287525380990) < 1e-6        # -(sqrt(2)-1)^2
+    assert np.allclose(M.getvalue(), [2 ** -0.5, 2 ** -0.5], atol=1e-3)
