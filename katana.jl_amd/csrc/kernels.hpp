@@ -811,6 +811,13 @@ __global__ __launch_bounds__(kBlock) void k_scale_vec(int64_t n, double* __restr
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) z[i] *= s;
 }
+// out = a / sqrt(*normsq)  (normalisation of the power iteration without a host round trip)
+__global__ __launch_bounds__(kBlock) void k_normalize(int64_t n, const double* __restrict__ a, const double* __restrict__ normsq,
+                                                      double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const double s = normsq[0];
+    if (i < n) out[i] = (s > 0.0) ? a[i] / sqrt(s) : 0.0;
+}
 __global__ __launch_bounds__(kBlock) void k_fill(int64_t n, double* __restrict__ z, double v) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) z[i] = v;

@@ -15,3 +15,4 @@ print("%s: gen %.1fs load %.2fs solve %.3fs %s iters=%d cuts=%d lp_rows=%d obj=%
     name, tg, tl, ts, st, m.numiters(), m.numcuts(), m.lp_num_rows(), m.getobjval(), inst.opt_obj,
     abs(m.getobjval() - inst.opt_obj) / max(1, abs(inst.opt_obj)), m.stat("pdhg_iters"), m.stat("lp_time_s"), m.stat("sep_time_s"),
     np.max(np.abs(x - inst.xhat))), flush=True)
+print("lp setup %.4fs of lp %.4fs over %d solves" % (m.stat("lp_setup_time_s"), m.stat("lp_time_s"), m.stat("lp_solves")))
