@@ -120,3 +120,16 @@ def test_cut_pool_purging_keeps_the_answer():
     assert purge.numcuts() >= purge.lp_num_rows()                       # numcuts stays cumulative (model.jl:333)
     assert abs(purge.getobjval() - keep.getobjval()) <= OBJ_RTOL * max(1.0, abs(keep.getobjval()))
     assert max_nl_violation(inst, purge.getsolution()) <= 1e-6 * (1 + 1e-6)
+
+
+@pytest.mark.parametrize("name,seed", [("cfg2", 1), ("cfg2", 2), ("cfg2", 3), ("cfg2", 4), ("cfg3", 1), ("cfg3", 3),
+                                       ("cfg5_one", 2)])
+def test_full_size_configs_other_seeds(name, seed):
+    """BASELINE.json configs at full size, seeds 1-4: planted optimum, feasibility, x"""
+    inst = ktn.instances.make_config(name, seed=seed)
+    m = hip_load_instance(ktn, inst)
+    assert m.optimize() == "Optimal"
+    x = m.getsolution()
+    assert abs(m.getobjval() - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+    assert max_nl_violation(inst, x) <= 1e-6 * (1 + 1e-6)
+    assert np.max(np.abs(x - inst.xhat)) <= 1e-3
