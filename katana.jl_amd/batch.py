@@ -12,9 +12,16 @@ from .nlp import SeparableNLP
 from .solver import NonlinearModel
 
 
-def solve_batch(solver, instances, threads=16, describe=SeparableNLP):
+def solve_batch(solver, instances, threads=16, describe=SeparableNLP, fused=False):
     """Solve every instance; returns (results, wall_seconds).  results[i] = dict(status, objval, iters,
-    numcuts, x) in the order of `instances`."""
+    numcuts, x) in the order of `instances`.
+
+    fused=True solves the block-diagonal union of the instances as ONE problem (instances.fuse_instances): the
+    cutting-plane loop, the sweep and every PDHG launch then serve the whole batch at once, and the stop rule --
+    every nonlinear row of every instance within f_tol -- is the conjunction of the per-instance stop rules.
+    Iteration counts are then those of the union (the slowest instance), objectives are split per instance."""
+    if fused:
+        return _solve_fused(solver, instances)
     def work(inst):
         m = NonlinearModel(solver)
         m.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense,
@@ -29,4 +36,23 @@ def solve_batch(solver, instances, threads=16, describe=SeparableNLP):
     else:
         with ThreadPoolExecutor(max_workers=threads) as ex:
             out = list(ex.map(work, instances))
+    return out, time.perf_counter() - t0
+
+
+def _solve_fused(solver, instances):
+    import numpy as np
+    from .instances import atom_value_deriv, fuse_instances
+    t0 = time.perf_counter()
+    big, offs = fuse_instances(instances)
+    m = NonlinearModel(solver)
+    m.loadproblem(big.n, big.num_constr, big.l_var, big.u_var, big.l_constr, big.u_constr, big.sense, SeparableNLP(big))
+    status = m.optimize()
+    x = m.getsolution()
+    out = []
+    for k, inst in enumerate(instances):
+        xi = x[offs[k]:offs[k + 1]]
+        val, _ = atom_value_deriv(np.asarray(inst.obj_kind), np.asarray(inst.obj_p0), np.asarray(inst.obj_p1),
+                                  xi[np.asarray(inst.obj_col)])
+        out.append(dict(status=status, objval=float(val.sum() + inst.obj_const), iters=m.numiters(), numcuts=None, x=xi,
+                        pdhg_iters=m.stat("pdhg_iters")))
     return out, time.perf_counter() - t0

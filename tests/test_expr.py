@@ -79,3 +79,20 @@ def test_instance_generator_plants_a_kkt_vertex():
     # determinism
     again = ktn.instances.make_instance(n=600, m_nl=60, k=16, family="explog", seed=5)
     assert np.array_equal(again.p0, inst.p0) and np.array_equal(again.col, inst.col)
+
+
+def test_fuse_instances_is_block_diagonal():
+    a = ktn.instances.make_instance(n=50, m_nl=6, k=4, family="quad", seed=1)
+    b = ktn.instances.make_instance(n=70, m_nl=9, k=5, family="explog", seed=2)
+    f, offs = ktn.instances.fuse_instances([a, b])
+    assert f.n == 120 and f.m_lin == a.m_lin + b.m_lin and f.m_nl == 15 and list(offs) == [0, 50, 120]
+    assert abs(f.opt_obj - (a.opt_obj + b.opt_obj)) < 1e-12
+    rp = f.rowptr
+    # linear rows of a, then of b, then NL rows of a, then of b; columns shifted by the block offset
+    la = a.rowptr[a.m_lin]
+    assert np.array_equal(f.col[:la], a.col[:la])
+    lb = b.rowptr[b.m_lin]
+    assert np.array_equal(f.col[la:la + lb], b.col[:lb] + 50)
+    first_nl_b = rp[f.m_lin + a.m_nl]
+    assert np.array_equal(f.col[first_nl_b:], b.col[lb:] + 50) and np.array_equal(f.p0[first_nl_b:], b.p0[lb:])
+    assert np.all(f.col[rp[f.m_lin]:first_nl_b] < 50)

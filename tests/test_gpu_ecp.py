@@ -133,3 +133,16 @@ def test_full_size_configs_other_seeds(name, seed):
     assert abs(m.getobjval() - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
     assert max_nl_violation(inst, x) <= 1e-6 * (1 + 1e-6)
     assert np.max(np.abs(x - inst.xhat)) <= 1e-3
+
+
+def test_fused_batch_mode_solves_every_instance():
+    """throughput mode as ONE block-diagonal problem: every launch serves the whole batch; each instance ends
+    within f_tol and at its own planted optimum"""
+    insts = [ktn.instances.make_instance(n=300, m_nl=30, k=8, family="explog", seed=200 + s) for s in range(24)]
+    res, _ = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts, fused=True)
+    assert len(res) == len(insts)
+    for r, inst in zip(res, insts):
+        assert r["status"] == "Optimal"
+        assert abs(r["objval"] - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+        assert max_nl_violation(inst, r["x"]) <= 1e-6 * (1 + 1e-6)
+        assert np.max(np.abs(r["x"] - inst.xhat)) <= 1e-3
