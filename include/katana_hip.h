@@ -89,7 +89,7 @@ typedef struct {
     int32_t vis_data;       /* 0      feature :VisData (src/model.jl:1-4,29-31)     */
     int32_t device;         /* -1     HIP device ordinal; -1 = current device       */
     /* GPU LP (restarted reflected Halpern PDHG) */
-    int32_t lp_max_iter;    /* 2000000 PDHG iterations per LP solve                 */
+    int32_t lp_max_iter;    /* 10000000 PDHG iterations per LP solve                */
     int32_t lp_check_every; /* 64      iterations between KKT checks                */
     int32_t lp_ruiz_iters;  /* 10                                                   */
     double  lp_tol_scale;   /* 0.1     LP row tolerance = lp_tol_scale * max viol.  */
