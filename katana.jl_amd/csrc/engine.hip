@@ -24,6 +24,7 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "dense_lp.hpp"
 #include "prims.hpp"
 
 namespace ktn {
@@ -131,6 +132,7 @@ struct LpResult {
     int status = KTN_STATUS_NONE;   // OPTIMAL / USERLIMIT
     int64_t iters = 0;
     double pobj = 0.0, dobj = 0.0, row_viol = 0.0, gap = 0.0;
+    bool exact = false;             // solved by the exact small-LP kernel: no tolerance tightening needed
 };
 
 struct Engine {
@@ -194,6 +196,10 @@ struct Engine {
     DBuf<char> d_sorttmp;
     DBuf<double> dr, dc, statr, statc, ch, lh, uh, loh, hih, xh, yh, x0h, y0h, xth, yth, xbar, pv, pw, box;
     DBuf<double> partials, chkout, power_v;
+    // exact small-LP path (dense_lp.hpp)
+    int64_t lp_iter_budget = 0, dense_credit = 0, dense_run = 0;
+    DBuf<int32_t> ds_W, ds_valid;
+    DBuf<double> ds_dense, ds_out;
     DBuf<int32_t> d_longrows;
     DBuf<double> d_sched;               // [0, kMaxChunk+2): plain chunks, [kMaxChunk+2, ...+4): check iterations
     double* h_sched = nullptr;          // pinned, same two regions
@@ -430,6 +436,8 @@ struct Engine {
     const double* cur_sched = nullptr;
     void compute_scaling(bool identity);
     LpResult lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling = false);
+    LpResult lp_solve_core(double tol_p, double tol_g, int mode, bool identity_scaling);
+    bool lp_solve_dense(LpResult* R);
     void pdhg_raw(const double* x0, const double* y0, double eta, double omega_, int64_t iters, double* x_out,
                   double* y_out);
 
@@ -742,6 +750,8 @@ void Engine::reset() {
     d_age.resize((size_t)std::max<int64_t>(M, 1), stream);
     d_age.zero(stream);
     lp_dirty = true; have_omega = false; have_precompute = false; sharded_rows = false;
+    if (ds_valid.n) ds_valid.zero(stream);
+    dense_credit = dense_run = 0;
     power_v.n = 0;
     status = KTN_STATUS_NONE; lp_status = KTN_STATUS_OPTIMAL;
     iter = 0; soltime = 0.0; objval = std::numeric_limits<double>::quiet_NaN();
@@ -812,6 +822,7 @@ void Engine::purge_cuts() {
     lp_y.swap(lp_y2); d_age.swap(d_age2); d_cutprev.swap(d_cutprev2);
     lp_rowptr.n = (size_t)m_new + 1; lp_col.n = lp_val.n = (size_t)nnz_new;
     lp_lo.n = lp_hi.n = lp_y.n = d_age.n = d_cutprev.n = (size_t)m_new;
+    if (ds_valid.n) ds_valid.zero(stream);          // row indices changed: the dense path's working set is void
     stats["purged_rows"] += (double)(m - m_new);
     stats["purges"] += 1.0;
     M = m_new; NNZ = nnz_new;
@@ -889,7 +900,88 @@ double* Engine::upload_sched(double tau, double sigma, int64_t k0, int nw, bool 
     return d_sched.p + off;
 }
 
+// LP dispatch.  The first-order method is the default: on the large sparse LPs of the hot path it is the only
+// option, and on small ones its solutions sit in the middle of the optimal face, which Kelley's method likes
+// (test/misc.jl 501: tens of iterations instead of thousands from simplex vertices).  Where it STALLS -- several
+// nearly parallel cuts active at a curved optimum, DESIGN.md section 5 -- and the LP has at most kDenseMaxN
+// columns, the exact kernel finishes the solve; each stall doubles the number of following solves that go to
+// the exact kernel directly.
 LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling) {
+    const bool dense_ok = mode == 0 && !identity_scaling && prm.lp_dense_after != 0 && n_lp >= 1 && n_lp <= kDenseMaxN &&
+                          M * n_lp <= 8000000;
+    if (!dense_ok) return lp_solve_core(tol_p, tol_g, mode, identity_scaling);
+    if (prm.lp_dense_after < 0 || dense_credit > 0) {
+        if (dense_credit > 0) --dense_credit;
+        LpResult R;
+        if (lp_solve_dense(&R)) return R;
+        stats["dense_lp_fallbacks"] += 1.0;
+        return lp_solve_core(tol_p, tol_g, mode, identity_scaling);
+    }
+    lp_iter_budget = prm.lp_dense_after;
+    LpResult R = lp_solve_core(tol_p, tol_g, mode, identity_scaling);
+    lp_iter_budget = 0;
+    if (R.status != KTN_STATUS_USERLIMIT) return R;
+    stats["lp_stalls"] += 1.0;
+    LpResult D;
+    if (lp_solve_dense(&D)) {
+        dense_run = std::min<int64_t>(2 * std::max<int64_t>(dense_run, 1), 1 << 20);
+        dense_credit = dense_run;
+        return D;
+    }
+    stats["dense_lp_fallbacks"] += 1.0;
+    return lp_solve_core(tol_p, tol_g, mode, identity_scaling);
+}
+
+// Exact solve of a small LP by the dual active-set kernel (dense_lp.hpp).  Returns false when the kernel
+// gives up (singular working set, pivot limit, or an artificial bound left in the optimal working set, i.e.
+// the optimal face is unbounded in some zero-cost direction): the caller then runs the first-order method.
+bool Engine::lp_solve_dense(LpResult* R) {
+    auto t0 = std::chrono::steady_clock::now();
+    const int n = (int)n_lp;
+    const int64_t m = M;
+    ds_dense.resize((size_t)std::max<int64_t>(m, 1) * n, stream);
+    ds_out.resize(4, stream);
+    if (ds_W.n != (size_t)n) {
+        ds_W.resize(n, stream);
+        ds_valid.resize(1, stream);
+        ds_valid.zero(stream);
+    }
+    lp_y.resize((size_t)std::max<int64_t>(m, 1), stream);
+    lp_y.n = (size_t)m;
+    DenseLpIO P;
+    P.n = n; P.m = m; P.rowptr = lp_rowptr.p; P.col = lp_col.p; P.val = lp_val.p; P.lo = lp_lo.p; P.hi = lp_hi.p;
+    P.l = lp_l.p; P.u = lp_u.p; P.c = lp_c.p; P.sgn = (sense == KTN_MAX) ? -1.0 : 1.0;
+    P.dense = ds_dense.p; P.W = ds_W.p; P.Wvalid = ds_valid.p; P.x = lp_x.p; P.y = lp_y.p; P.out = ds_out.p;
+    P.max_pivots = 200 + 20 * n + (int)std::min<int64_t>(m, 100000);
+    P.tol = 1e-9;
+    hipLaunchKernelGGL(k_dense_lp, dim3(1), dim3(256), 0, stream, P);
+    check_launch();
+    double out[4];
+    KTN_HIP(hipMemcpyAsync(out, ds_out.p, sizeof(out), hipMemcpyDeviceToHost, stream));
+    sync();
+    stats["dense_lp_solves"] += 1.0;
+    stats["dense_lp_pivots"] += out[1];
+    stats["lp_solves"] += 1.0;
+    stats["lp_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const int st = (int)out[0];
+    if (st == 0) {
+        R->status = KTN_STATUS_OPTIMAL;
+        R->iters = (int64_t)out[1];
+        R->pobj = R->dobj = out[2];
+        R->row_viol = 0.0; R->gap = 0.0;
+        R->exact = true;
+        objval = P.sgn * out[2] + c0;
+        return true;
+    }
+    if (st == 1) {
+        R->status = KTN_STATUS_INFEASIBLE;
+        R->iters = (int64_t)out[1];
+        return true;
+    }
+    return false;
+}
+
+LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identity_scaling) {
     auto t0 = std::chrono::steady_clock::now();
     LpResult R;
     if (lp_dirty) rebuild_csc();
@@ -974,7 +1066,7 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
     double r0 = 0.0, r_prev = 0.0;
     static const bool dbg_lp = std::getenv("KTN_DEBUG_LP") != nullptr;
     R.status = KTN_STATUS_USERLIMIT;
-    const int64_t max_it = prm.lp_max_iter;
+    const int64_t max_it = lp_iter_budget > 0 ? std::min<int64_t>(lp_iter_budget, prm.lp_max_iter) : prm.lp_max_iter;
     const int chk = std::max(1, prm.lp_check_every);
     drop_graph();      // pointers, sizes and group widths of this LP differ from the last one
     const int plain_len = std::min(chk - 1, (int)kMaxChunk);
@@ -1270,7 +1362,7 @@ void Engine::step(int32_t* done) {
     const bool sat_now = (nviol == 0);
     // inexact-LP rule (DESIGN.md "LP tolerance schedule"): all rows satisfied only counts once
     // the LP itself was solved to the floor tolerance
-    if (sat_now && tol_p > floor_p * (1.0 + 1e-12)) last_maxviol = 0.0;
+    if (sat_now && !R.exact && tol_p > floor_p * (1.0 + 1e-12)) last_maxviol = 0.0;
     else allsat = sat_now;
     const double obj = objval;                                           // model.jl:287-289
     const double obj_delta = std::fabs((obj_prev - obj) / obj);
@@ -1328,6 +1420,7 @@ void ktn_default_params(ktn_params* p) {
     p->lp_tol_scale = 0.1; p->lp_tol_floor = 0.3; p->lp_tol_cap = 0.1; p->lp_gap_floor = 1e-7; p->lp_gap_cap = 1e-2;
     p->lp_dual_inherit = 1; p->profile = 0;
     p->purge_age = 2; p->purge_margin = 1e-3; p->purge_min_frac = 0.05; p->purge_min_rows = 2000;
+    p->lp_dense_after = 20000;
 }
 
 int ktn_create(const ktn_params* p, ktn_handle* out) {
@@ -1603,6 +1696,7 @@ int ktn_lp_truncate(ktn_handle h, int64_t nrows) {
         e->numcuts -= (e->M - nrows);
         e->M = nrows; e->NNZ = base;
         e->sharded_rows = true;
+        if (e->ds_valid.n) e->ds_valid.zero(e->stream);
         e->lp_rowptr.n = (size_t)nrows + 1; e->lp_col.n = e->lp_val.n = (size_t)base;
         e->lp_lo.n = e->lp_hi.n = e->lp_y.n = (size_t)nrows;
         e->lp_dirty = true;

@@ -107,3 +107,99 @@ def test_infeasible_lp_status_is_passed_through():
     lm = LinearModel(); lm.add_variables([-5, -5], [5, 5]); lm.set_objective("Min", [0, 1], [1.0, 1.0])
     lm.add_rows([0, 2, 4, 5], [0, 1, 0, 1, 0], [1, 1, 1, 2, 1], [3, -np.inf, -np.inf], [np.inf, 1, 0.5])
     assert lm.solve() == "Infeasible"
+
+
+# ---- exact small-LP kernel (csrc/dense_lp.hpp); lp_dense_after < 0 sends every LP of <= 32 columns to it ----------
+
+def _random_small_lp(rng, n):
+    """bounded polytope around the origin: 6n inequality rows, a few range / equality rows, mixed variable bounds"""
+    m_in, m_rg, m_eq = 6 * n, 3, min(2, n - 1)
+    A = rng.normal(size=(m_in + m_rg + m_eq, n))
+    A[rng.random(A.shape) < 0.3] = 0.0
+    A[:, 0] += 0.1                                    # no empty row
+    xf = rng.normal(size=n) * 0.3                     # a feasible point
+    ax = A @ xf
+    lo = np.full(len(A), -np.inf); hi = ax + rng.uniform(0.5, 2.0, len(A))
+    lo[m_in:m_in + m_rg] = ax[m_in:m_in + m_rg] - rng.uniform(0.5, 2.0, m_rg)
+    lo[m_in + m_rg:] = hi[m_in + m_rg:] = ax[m_in + m_rg:]
+    l = np.full(n, -np.inf); u = np.full(n, np.inf)
+    kind = rng.integers(0, 4, n)                      # 0 free, 1 lower only, 2 upper only, 3 boxed
+    l[(kind == 1) | (kind == 3)] = xf[(kind == 1) | (kind == 3)] - 1.0
+    u[(kind == 2) | (kind == 3)] = xf[(kind == 2) | (kind == 3)] + 1.0
+    return A, lo, hi, l, u, rng.normal(size=n)
+
+
+@pytest.mark.parametrize("n,sense,seed", [(1, "Min", 0), (3, "Min", 1), (3, "Max", 2), (12, "Min", 3), (32, "Max", 4), (32, "Min", 5)])
+def test_exact_small_lp_kernel_matches_highs(n, sense, seed):
+    from oracle.lp import LinearModel
+    rng = np.random.default_rng(seed)
+    A, lo, hi, l, u, c = _random_small_lp(rng, n)
+    M = ktn.Model(solver=ktn.KatanaSolver(log_level=0, lp_dense_after=-1))
+    V = [ktn.var(j) for j in range(n)]
+    for j in range(n):
+        M.variable(l[j], u[j])
+    M.objective(sense, sum((float(c[j]) * V[j] for j in range(1, n)), float(c[0]) * V[0]))
+    for i in range(len(A)):
+        M.constraint((sum((float(A[i, j]) * V[j] for j in range(1, n)), float(A[i, 0]) * V[0]), lo[i], hi[i]))
+    lm = LinearModel()
+    lm.add_variables(l, u)
+    lm.set_objective(sense, np.arange(n), c, 0.0)
+    rp = np.arange(0, (len(A) + 1) * n, n)
+    lm.add_rows(rp, np.tile(np.arange(n), len(A)), A.ravel(), lo, hi)
+    want = lm.solve()
+    got = M.solve()
+    im = M.internal_model
+    assert got == want
+    if want != "Optimal":
+        return
+    # (pdhg_iters may be > 0: with unboxed variables the recession-cone LP is checked by the first-order path first)
+    assert im.stat("dense_lp_solves") == 1 and im.stat("dense_lp_fallbacks") == 0
+    assert abs(M.getobjectivevalue() - lm.getobjval()) <= 1e-9 * max(1.0, abs(lm.getobjval()))
+    x = np.asarray(M.getvalue())
+    ax = A @ x
+    assert np.max(np.maximum(ax - hi, lo - ax)) <= 1e-8 and np.all(x >= l - 1e-9) and np.all(x <= u + 1e-9)
+    # multipliers: dual objective equals the primal one (strong duality with exact arithmetic up to rounding)
+    y = im.lp_duals()
+    r = (c if sense == "Min" else -c) - A.T @ y
+    dobj = np.sum(np.where(y > 0, lo, hi)[y != 0] * y[y != 0]) + np.sum(np.where(r > 0, l, u)[np.abs(r) > 1e-9] * r[np.abs(r) > 1e-9])
+    pobj = float((c if sense == "Min" else -c) @ x)
+    assert abs(dobj - pobj) <= 1e-7 * max(1.0, abs(pobj))
+
+
+def test_exact_kernel_reports_infeasible_small_lp():
+    x, y = ktn.var(0), ktn.var(1)
+    M = ktn.Model(solver=ktn.KatanaSolver(log_level=0, lp_dense_after=-1))
+    M.variable(-5, 5); M.variable(-5, 5)
+    M.objective("Min", x + y)
+    M.constraint(x + y >= 3.0)
+    M.constraint(x + 2 * y <= 1.0)
+    M.constraint(x - 0 * y <= 0.5)
+    assert M.solve() == "Infeasible"
+    assert M.internal_model.stat("dense_lp_fallbacks") == 0
+
+
+@pytest.mark.parametrize("kid", ["101_01", "501_01_n4"])
+def test_exact_lp_reproduces_the_simplex_trajectory(kid):
+    """with exact vertex LP solutions the ECP iteration count equals the oracle's (HiGHS dual simplex) on models
+    whose LPs have a unique optimal vertex"""
+    from helpers import hip_model_from_kat, oracle_solve_kat
+    from kat_util import load_kats
+    k = [m for m in load_kats() if m["id"] == kid][0]
+    om = oracle_solve_kat(k)
+    M = hip_model_from_kat(ktn, k, lp_dense_after=-1)
+    assert M.solve() == om.status == "Optimal"
+    assert M.internal_model.numiters() == om.numiters()
+    assert abs(M.getobjectivevalue() - om.getobjval()) <= 1e-7
+
+
+def test_stalled_first_order_lp_hands_over_to_the_exact_kernel():
+    """test/2d.jl 107_01-like flat optimum: the first-order LP exceeds a (small) iteration budget, the exact kernel
+    finishes the solve and the answer is the reference's"""
+    from helpers import hip_model_from_kat
+    from kat_util import isapprox, load_kats
+    k = [m for m in load_kats() if m["id"] == "108_01"][0]
+    M = hip_model_from_kat(ktn, k, lp_dense_after=2000)
+    assert M.solve() == "Optimal"
+    im = M.internal_model
+    assert im.stat("lp_stalls") >= 1 and im.stat("dense_lp_solves") >= 1
+    assert isapprox(M.getobjectivevalue(), k["expect"]["obj"], 1e-6, 1e-6)
