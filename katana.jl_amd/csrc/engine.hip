@@ -164,6 +164,14 @@ struct Engine {
     DBuf<uint8_t> d_rowkind, d_padzero;
     DBuf<int32_t> d_colk;
     DBuf<double2> d_pp;
+    // block-major copy of the long rows for the column-blocked sweep (k_sep_eval_blk)
+    bool blk_on = false;
+    int blk_nb = 0, blk_cfg = 0, blk_cols = kBlkCols, blk_wg_per_cu = 2, num_cus = 256;
+    DBuf<int32_t> d_bcolk;
+    DBuf<double2> d_bpp;
+    DBuf<int64_t> d_bseg;
+    DBuf<int4> d_bkind;
+    DBuf<SepPartial> d_part;
     DBuf<double> d_rconst, d_lb, d_ub, d_nodec, d_nodeval, d_nodeadj;
     DBuf<int32_t> d_nlrows, d_allrows, d_taperows_all, d_taperows_nl;
     // sweep state
@@ -240,6 +248,10 @@ struct Engine {
             device = prm.device;
         } else {
             KTN_HIP(hipGetDevice(&device));
+        }
+        {
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) num_cus = cus;
         }
         KTN_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         partials.resize((size_t)kRedBlocks * kChkQ * 2, stream);
@@ -366,7 +378,26 @@ struct Engine {
         SweepOut O = sweep_view();
         KTN_HIP(hipMemsetAsync(d_scal.p, 0, sizeof(double), stream));
         KTN_HIP(hipMemsetAsync(d_anynf.p, 0, sizeof(int32_t), stream));
-        if (prm.profile) {
+        if (blk_on) {
+            // long rows: column-blocked evaluation through LDS, then the block-order combination
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (prm.profile) {
+                const size_t ea = ev_get(), eb = ev_get();
+                e0 = ev_pool[ea]; e1 = ev_pool[eb];
+                ev_recs.push_back({2, ea, eb, sweep_bytes});
+            }
+#define KTN_BLK_LAUNCH(G, BC, BS, U)                                                                                      \
+    hipExtLaunchKernelGGL((k_sep_eval_blk<G, BC, BS, U>), dim3((unsigned)(num_cus * blk_wg_per_cu)), dim3(BS), 0, stream, e0, nullptr, 0, \
+                          d_bcolk.p, d_bpp.p, d_bseg.p, d_bkind.p, m_nl, blk_nb, d_x, n_lp, d_part.p)
+            switch (blk_cfg) {       // KTN_BLK_CFG: tuning variants kept for the next round's experiments
+                case 1: KTN_BLK_LAUNCH(16, 8192, 512, 4); break;
+                case 2: KTN_BLK_LAUNCH(16, 16384, 1024, 4); break;
+                default: KTN_BLK_LAUNCH(8, 8192, 512, 4); break;
+            }
+#undef KTN_BLK_LAUNCH
+            hipExtLaunchKernelGGL(k_sep_combine, dim3(ceil_div(m_nl, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, P, d_nlrows.p, m_nl, blk_nb,
+                                  d_part.p, f_tol, O);
+        } else if (prm.profile) {
             const size_t ea = ev_get(), eb = ev_get();
             LAUNCH_G_EV(grp_sweep, k_sep_eval, m_nl, stream, ev_pool[ea], ev_pool[eb], P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O);
             ev_recs.push_back({2, ea, eb, sweep_bytes});
@@ -638,6 +669,70 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     d_nlrows.upload(h_nlrows, stream);
     grp_sweep = pick_group(m_nl ? (double)nnz_nl / (double)m_nl : 4.0);
     if (grp_sweep < 8) grp_sweep = 8;
+    // Long rows (hundreds of entries or more): block-major copy for the column-blocked sweep.  Needs every separable
+    // NL row sorted by column (the segments are found by binary search).
+    {
+        // Measured on cfg3_hbm (2e7 entries, 2048 per row): exp/log atoms 156 -> 123 us, quadratic atoms 171 -> 114 us.
+        // KTN_SWEEP_BLOCKED=0 switches it off (tests compare the two paths).
+        if (const char* c = std::getenv("KTN_BLK_CFG")) blk_cfg = std::atoi(c);
+        blk_cols = (blk_cfg == 2) ? 16384 : 8192;
+        blk_wg_per_cu = (blk_cfg == 2) ? 1 : 2;
+        const char* env = std::getenv("KTN_SWEEP_BLOCKED");
+        blk_on = m_nl > 0 && n_lp >= 2 * blk_cols && (double)nnz_nl / (double)m_nl >= 256.0;
+        if (env) blk_on = blk_on && std::atoi(env) != 0;
+        blk_nb = ceil_div(n_lp, blk_cols);
+        if (blk_on && (double)(m_nl + 1) * blk_nb > 4e8) blk_on = false;
+        for (size_t si = 0; blk_on && si < h_nlrows.size(); ++si) {
+            const int64_t r = h_nlrows[si];
+            if (h_rowkind[r] != KTN_ROW_SEP) continue;
+            for (int64_t e = h_rowptr[r] + 1; e < h_rowptr[r + 1]; ++e)
+                if (h_col[e] < h_col[e - 1]) { blk_on = false; break; }
+        }
+        d_bcolk.release(); d_bpp.release(); d_bseg.release(); d_bkind.release(); d_part.release();
+        if (blk_on) {
+            std::vector<int64_t> bseg((size_t)(m_nl + 1) * blk_nb);
+            std::vector<int4> bkind((size_t)(m_nl + 1) * blk_nb, make_int4(0, 0, 0, 0));
+            std::vector<int32_t> bcolk((size_t)nnz_nl);
+            std::vector<double2> bpp((size_t)nnz_nl);
+            // cut[si * (NB + 1) + b]: first entry of row si with column >= b * blk_cols
+            std::vector<int64_t> cut((size_t)m_nl * (blk_nb + 1));
+            for (int64_t si = 0; si < m_nl; ++si) {
+                const int64_t r = h_nlrows[si];
+                const int32_t* cb = h_col.data() + h_rowptr[r];
+                const int32_t* ce = (h_rowkind[r] == KTN_ROW_SEP) ? h_col.data() + h_rowptr[r + 1] : cb;   // tape rows: empty
+                for (int b = 0; b <= blk_nb; ++b) {
+                    const int64_t c0 = (int64_t)b * blk_cols;
+                    cut[(size_t)si * (blk_nb + 1) + b] =
+                        h_rowptr[r] + (std::lower_bound(cb, ce, c0, [](int32_t a, int64_t v) { return (int64_t)a < v; }) - cb);
+                }
+            }
+            int64_t w = 0;
+            for (int b = 0; b < blk_nb; ++b) {
+                for (int64_t si = 0; si < m_nl; ++si) {
+                    bseg[(size_t)b * (m_nl + 1) + si] = w;
+                    const int64_t eb = cut[(size_t)si * (blk_nb + 1) + b], ee = cut[(size_t)si * (blk_nb + 1) + b + 1];
+                    const int64_t w0 = w;
+                    int32_t kstart[KTN_ATOM_NEGLOG + 1];
+                    for (int kd = 0; kd <= KTN_ATOM_NEGLOG; ++kd) {      // segment grouped by atom kind (stable)
+                        kstart[kd] = (int32_t)(w - w0);
+                        for (int64_t e = eb; e < ee; ++e) {
+                            if (akind[e] != kd) continue;
+                            bcolk[(size_t)w] = h_col[e] | ((int32_t)kd << kKindShift);
+                            bpp[(size_t)w] = make_double2(p0[e], p1[e]);
+                            ++w;
+                        }
+                    }
+                    bkind[(size_t)b * (m_nl + 1) + si] = make_int4(kstart[KTN_ATOM_QUAD], kstart[KTN_ATOM_EXP], kstart[KTN_ATOM_NEGLOG], 0);
+                }
+                bseg[(size_t)b * (m_nl + 1) + m_nl] = w;
+            }
+            d_bcolk.upload(bcolk.data(), (size_t)w, stream);
+            d_bpp.upload(bpp.data(), (size_t)w, stream);
+            d_bseg.upload(bseg, stream);
+            d_bkind.upload(bkind, stream);
+            d_part.resize((size_t)m_nl * blk_nb, stream);
+        }
+    }
     // algorithmic bytes of one evaluation pass over the NL rows (DESIGN.md "sweep bytes")
     sweep_bytes = (double)nnz_nl * (4 + 16) + 8.0 * (m_nl + 1) + 8.0 * n_lp + 8.0 * 4 * m_nl + 16.0 * m_nl;
     const size_t mm = (size_t)std::max<int64_t>(m_ext, 1);

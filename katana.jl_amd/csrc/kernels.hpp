@@ -26,6 +26,7 @@ constexpr int kRedBlocks = 256;   // blocks of the two-stage deterministic reduc
 constexpr int kChkQ = 16;         // quantities per check partial
 constexpr int kKindShift = 29;    // packed (col | kind << 29): columns < 2^29
 constexpr int kColMask = (1 << kKindShift) - 1;
+constexpr int kBlkCols = 8192;    // columns of x* staged in LDS per workgroup of the column-blocked sweep (64 KB)
 
 // ---------------------------------------------------------------- small helpers ----
 template <int G>
@@ -171,6 +172,127 @@ __global__ __launch_bounds__(kBlock) void k_sep_eval(NlpDev P, const int32_t* __
                 if (nf) atomicOr(O.any_nonfin, 1);
             }
         }
+    }
+}
+
+// ---- column-blocked evaluation for LONG rows (HBM-resident Jacobians) ------------------
+// k_sep_eval gathers x*[col] from L2: with thousands of entries per row every 8-byte gather pulls its own 128-byte
+// line into the L1 and the kernel is bound by that traffic at a third of the HBM peak.  For such instances the
+// engine keeps a second, BLOCK-MAJOR copy of the packed Jacobian: for each block of kBlkCols columns, the entries
+// of all rows that fall into the block, row after row.  A workgroup owns (block b, a tile of rows): it stages
+// x*[b*BC .. (b+1)*BC) in LDS once, streams one contiguous run of entries and gathers from LDS.  Per (row, block)
+// partials are combined in block order by k_sep_combine, so every sum keeps a fixed order (bitwise reproducible).
+struct SepPartial { double g, dot, mx, nf; };
+
+// one kind-uniform run [beg, end) of a (row, block) segment; x* comes from the LDS copy of the block
+template <int G, int KIND, int kU>
+__device__ __forceinline__ void blk_run(const int32_t* __restrict__ bcolk, const double2* __restrict__ bpp, int64_t beg,
+                                        int64_t end, int lane, const double* xs, int64_t c0, double& acc_g, double& acc_dot,
+                                        double& mx, int& nf) {
+    for (int64_t e = beg + lane; e < end; e += kU * G) {
+        int ck[kU];
+        double2 q[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int64_t eu = e + (int64_t)u * G;
+            const bool on = eu < end;
+            ck[u] = on ? bcolk[eu] : -1;
+            q[u] = on ? bpp[eu] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (ck[u] >= 0) {
+                const double xv = xs[(ck[u] & kColMask) - c0];
+                double val, der;
+                atom_eval(KIND, q[u].x, q[u].y, xv, val, der);
+                acc_g += val;
+                acc_dot += xv * der;
+                mx = nanmax(mx, der);
+                nf |= !isfinite(der);
+            }
+        }
+    }
+}
+
+// Persistent grid (as many workgroups as fit the chip at once): the (block, row-tile) units are dealt out in contiguous,
+// equal chunks in block-major order, so the chip is balanced to within one tile whatever m_nl and n are, and a
+// workgroup reloads its x* block at most twice.
+template <int G, int BC, int BS, int kU>
+__global__ __launch_bounds__(BS) void k_sep_eval_blk(const int32_t* __restrict__ bcolk, const double2* __restrict__ bpp,
+                                                     const int64_t* __restrict__ bseg, const int4* __restrict__ bkind,
+                                                     int64_t m_nl, int NB, const double* __restrict__ x, int64_t n,
+                                                     SepPartial* __restrict__ part) {
+    __shared__ double xs[BC];
+    const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
+    constexpr int NG = BS / G;
+    const int64_t tiles = (m_nl + NG - 1) / NG;
+    const int64_t units = tiles * NB;
+    const int64_t per = (units + gridDim.x - 1) / gridDim.x;
+    const int64_t u0 = (int64_t)blockIdx.x * per;
+    const int64_t u1 = (u0 + per < units) ? u0 + per : units;
+    int cur_b = -1;
+    int64_t c0 = 0;
+    for (int64_t u = u0; u < u1; ++u) {
+        const int b = (int)(u / tiles);
+        const int64_t s = (u - (int64_t)b * tiles) * NG + grp;     // consecutive groups: consecutive rows, adjacent segments
+        if (b != cur_b) {                                          // (uniform over the workgroup)
+            __syncthreads();
+            c0 = (int64_t)b * BC;
+            for (int i = threadIdx.x; i < BC; i += BS) xs[i] = (c0 + i < n) ? x[c0 + i] : 0.0;
+            __syncthreads();
+            cur_b = b;
+        }
+        if (s >= m_nl) continue;
+        const int64_t* sp = bseg + (int64_t)b * (m_nl + 1);
+        const int64_t beg = sp[s], end = sp[s + 1];
+        const int4 kb = bkind[(int64_t)b * (m_nl + 1) + s];   // the segment is sorted by atom kind: starts of the QUAD / EXP / NEGLOG runs
+        double acc_g = 0.0, acc_dot = 0.0, mx = -__builtin_inf();
+        int nf = 0;
+        blk_run<G, KTN_ATOM_LIN, kU>(bcolk, bpp, beg, beg + kb.x, lane, xs, c0, acc_g, acc_dot, mx, nf);
+        blk_run<G, KTN_ATOM_QUAD, kU>(bcolk, bpp, beg + kb.x, beg + kb.y, lane, xs, c0, acc_g, acc_dot, mx, nf);
+        blk_run<G, KTN_ATOM_EXP, kU>(bcolk, bpp, beg + kb.y, beg + kb.z, lane, xs, c0, acc_g, acc_dot, mx, nf);
+        blk_run<G, KTN_ATOM_NEGLOG, kU>(bcolk, bpp, beg + kb.z, end, lane, xs, c0, acc_g, acc_dot, mx, nf);
+        acc_g = group_sum<G>(acc_g);
+        acc_dot = group_sum<G>(acc_dot);
+        mx = group_nanmax<G>(mx);
+        nf = group_or<G>(nf);
+        if (lane == 0) {
+            SepPartial o;
+            o.g = acc_g; o.dot = acc_dot; o.mx = mx; o.nf = nf ? 1.0 : 0.0;
+            part[(int64_t)b * m_nl + s] = o;             // [block][row]: k_sep_combine reads it coalesced
+        }
+    }
+}
+
+// block-order combination of the partials + the isconstrsat tail of k_sep_eval
+__global__ __launch_bounds__(kBlock) void k_sep_combine(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl, int NB,
+                                                        const SepPartial* __restrict__ part, double f_tol, SweepOut O) {
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= m_nl) return;
+    const int32_t r = nl_rows[s];
+    if (P.row_kind[r] != KTN_ROW_SEP) return;
+    double acc_g = 0.0, acc_dot = 0.0, mx = -__builtin_inf();
+    int nf = 0;
+    for (int b = 0; b < NB; ++b) {
+        const SepPartial q = part[(int64_t)b * m_nl + s];
+        acc_g += q.g;
+        acc_dot += q.dot;
+        mx = nanmax(mx, q.mx);
+        nf |= (q.nf != 0.0);
+    }
+    const double g = acc_g + P.rconst[r];
+    if (P.pad_zero[r]) mx = nanmax(mx, 0.0);
+    O.g[r] = g;
+    O.bconst[r] = g - acc_dot;
+    O.maxc[r] = mx;
+    O.nonfin[r] = nf;
+    const double lb = P.lb[r], ub = P.ub[r];
+    const bool sat = (g >= lb - f_tol) && (g <= ub + f_tol);   // separators.jl:120 (NaN -> violated)
+    O.flag[s] = sat ? 0 : 1;
+    O.cnt[s] = sat ? 0 : (P.rowptr[r + 1] - P.rowptr[r]);
+    if (!sat) {
+        atomic_max_nonneg(O.maxviol, fmax(g - ub, lb - g));
+        if (nf) atomicOr(O.any_nonfin, 1);
     }
 }
 

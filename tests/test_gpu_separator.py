@@ -201,3 +201,45 @@ def test_tape_rows_match_oracle_ad_on_reference_models(m):
             for e in range(sep.rowptr[r], sep.rowptr[r + 1]):
                 dense_h[r, sep.col[e]] += sep.jac[e]
         assert np.allclose(dense_h, dense_o, rtol=1e-13, atol=1e-13, equal_nan=True)
+
+
+@pytest.mark.parametrize("family", ["quad", "explog"])
+def test_column_blocked_sweep_of_long_rows_matches_the_gather_sweep(family, monkeypatch):
+    """rows with hundreds of entries: the block-major / LDS-staged evaluation (k_sep_eval_blk + k_sep_combine) finds the
+    same violated rows and emits the same cuts as k_sep_eval (sums in a different, fixed order: 1e-13 relative)"""
+    inst = ktn.instances.make_instance(n=20000, m_nl=120, k=700, family=family, seed=3)   # 3 column blocks of 8192
+    x = np.clip(inst.xhat * 1.5 + 0.7, inst.l_var, inst.u_var)
+    out = []
+    for blocked in ("0", "1"):
+        monkeypatch.setenv("KTN_SWEEP_BLOCKED", blocked)
+        m = hip_load_instance(ktn, inst)
+        sep = ktn.KatanaHipSeparator(m); sep.initialize()
+        m0 = m.lp_num_rows()
+        sep.precompute(x)
+        nv, mv = sep.sweep(1e-6)
+        out.append((nv, mv, m.lp_rows_from(m0)))
+    (nv0, mv0, r0), (nv1, mv1, r1) = out
+    assert nv0 == nv1 and nv0 > 0 and abs(mv0 - mv1) <= 1e-12 * max(1.0, abs(mv0))
+    assert np.array_equal(r0[0], r1[0]) and np.array_equal(r0[1], r1[1])
+    assert np.array_equal(r0[2], r1[2])                                     # coefficients: same arithmetic per entry
+    for a, b in ((r0[3], r1[3]), (r0[4], r1[4])):
+        a = np.asarray(a); b = np.asarray(b)
+        fin = np.isfinite(a)
+        assert np.array_equal(fin, np.isfinite(b))
+        assert np.allclose(a[fin], b[fin], rtol=1e-12, atol=1e-12)
+
+
+def test_ecp_solve_through_the_column_blocked_sweep(monkeypatch):
+    """a whole ECP solve on long rows (the blocked sweep is the default there) agrees with the gather sweep"""
+    inst = ktn.instances.make_instance(n=20000, m_nl=60, k=400, family="quad", seed=5)
+    res = []
+    for blocked in ("0", None):
+        if blocked is None:
+            monkeypatch.delenv("KTN_SWEEP_BLOCKED", raising=False)
+        else:
+            monkeypatch.setenv("KTN_SWEEP_BLOCKED", blocked)
+        m = hip_load_instance(ktn, inst)
+        assert m.optimize() == "Optimal"
+        res.append((m.getobjval(), m.numiters(), m.numcuts()))
+    assert abs(res[0][0] - res[1][0]) <= 1e-7 * max(1.0, abs(res[0][0]))
+    assert abs(res[0][0] - inst.opt_obj) <= 1e-5 * max(1.0, abs(inst.opt_obj))
