@@ -25,6 +25,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -40,6 +42,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-sweep-roofline", action="store_true")
     return ap.parse_args()
 
 
@@ -198,6 +201,29 @@ def main():
             "k_sep_eval": rf("sweep_eval", "k_sep_eval (separator sweep: g, cut constant, violation)"),
         }
 
+    # the separator sweep on the HBM-resident variant of the same workload (k = 2048 entries per
+    # NL row, 411 MB per pass); at cfg3's own k = 32 the sweep is a 10 us launch-latency-bound kernel.
+    sweep_roofline = None
+    if world == 1 and not args.no_roofline and not args.no_sweep_roofline and args.workload == "cfg3":
+        hb = ktn.instances.make_config("cfg3_hbm", seed=args.seed, vertex=False)
+        sm = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, device=local_rank, profile=1))
+        sm.loadproblem(hb.n, hb.num_constr, hb.l_var, hb.u_var, hb.l_constr, hb.u_constr, hb.sense, ktn.SeparableNLP(hb))
+        sep = ktn.KatanaHipSeparator(sm); sep.initialize()
+        xs = np.clip(hb.xhat + 0.05, hb.l_var, hb.u_var)
+        sep.precompute(xs)
+        for _ in range(3):
+            sep.sweep(1e-6)
+        b0 = {k: sm.stat(k) for k in ("sweep_eval_time_s", "sweep_eval_launches", "sweep_eval_bytes")}
+        for _ in range(20):
+            sep.sweep(1e-6)
+        dt, dn, db = (sm.stat(k) - b0[k] for k in ("sweep_eval_time_s", "sweep_eval_launches", "sweep_eval_bytes"))
+        ach = db / dt / 1e9
+        sweep_roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                          "kernel": "k_sep_eval_blk + k_sep_combine (column-blocked separator sweep)",
+                          "workload": "cfg3_hbm: n=%d, m_nl=%d exp/log rows, k=%d" % (hb.n, hb.m_nl, hb.meta["k"]),
+                          "launches": int(dn), "avg_launch_us": 1e6 * dt / dn, "algorithmic_bytes_per_launch": db / dn}
+        del sm, sep, hb
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
@@ -216,7 +242,7 @@ def main():
             "wall_to_ftol_s": wall_to_ftol, "ecp_iters_to_ftol": iters_to_ftol, "status": status, "objective": obj,
             "planted_objective": inst.opt_obj, "objective_relerr": abs(obj - inst.opt_obj) / max(1.0, abs(inst.opt_obj)),
             "pdhg_iters_per_step": pdhg_timed / args.steps, "solves_in_timed_region": len(solves),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "sweep_roofline": sweep_roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if dist is not None:
