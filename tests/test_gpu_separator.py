@@ -243,3 +243,39 @@ def test_ecp_solve_through_the_column_blocked_sweep(monkeypatch):
         res.append((m.getobjval(), m.numiters(), m.numcuts()))
     assert abs(res[0][0] - res[1][0]) <= 1e-7 * max(1.0, abs(res[0][0]))
     assert abs(res[0][0] - inst.opt_obj) <= 1e-5 * max(1.0, abs(inst.opt_obj))
+
+
+def _load_traces():
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_traces.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("tr", _load_traces(), ids=lambda t: t["id"])
+def test_replay_of_committed_oracle_traces(tr):
+    """tests/golden/kat_traces.json (made by tests/golden/make_trace_fixture.py): at every recorded LP point the device
+    sweep finds the same violated rows and appends the same cuts (coefficients after round_coefs, row bounds)"""
+    k = [m for m in load_kats() if m["id"] == tr["id"]][0]
+    n = len(k["vars"])
+    M = hip_model_from_kat(ktn, k)
+    d = M.build()
+    im = ktn.NonlinearModel(M.solver)
+    im.loadproblem(n, len(M.cons), M.lb, M.ub, [c[1] for c in M.cons], [c[2] for c in M.cons], M.sense, d)
+    sep = ktn.KatanaHipSeparator(im); sep.initialize()
+    for it in tr["iterations"]:
+        x = np.asarray(it["x"])
+        m0 = im.lp_num_rows()
+        sep.precompute(x)
+        g_want = np.asarray(it["g"])
+        g_got = sep.g[np.asarray(it["nl_rows"])]
+        assert np.allclose(g_got, g_want, rtol=1e-13, atol=1e-13), (g_got, g_want)
+        nviol, _ = sep.sweep(1e-6)
+        assert nviol == len(it["cuts"])
+        rowptr, col, val, lo, hi = im.lp_rows_from(m0)
+        for r, cut in enumerate(it["cuts"]):
+            dense = np.zeros(len(x))
+            for e in range(rowptr[r], rowptr[r + 1]):
+                dense[col[e]] += val[e]
+            assert np.allclose(dense, cut["coefs"], rtol=1e-12, atol=1e-12), (tr["id"], cut["row"], dense, cut["coefs"])
+            for got, want in ((lo[r], cut["lo"]), (hi[r], cut["hi"])):
+                assert (got == want) if not np.isfinite(want) else abs(got - want) <= 1e-12 * max(1.0, abs(want))

@@ -71,3 +71,24 @@ def test_pdlp_mirror_solves_small_lp():
     r = pm.solve_lp_halpern(A, np.array([-1.0, -1.0]), np.array([-2.0, -2.0]), np.array([2.0, 2.0]),
                             np.array([-np.inf, -0.5]), np.array([9.0, 0.5]), params=pm.PdlpParams(eps=1e-9))
     assert r["status"] == "Optimal" and abs(r["pobj"] + 2.25) < 1e-6
+
+
+def test_committed_trace_fixture_is_what_the_oracle_produces():
+    """tests/golden/kat_traces.json is regenerated in-process for two models and compared with the committed file"""
+    import importlib.util, json, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_trace_fixture", os.path.join(here, "golden", "make_trace_fixture.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    with open(os.path.join(here, "golden", "kat_traces.json")) as f:
+        committed = {t["id"]: t for t in json.load(f)}
+    from kat_util import load_kats
+    kats = {k["id"]: k for k in load_kats()}
+    for kid in ("101_01", "105_01"):
+        fresh = json.loads(json.dumps(mod.trace(kats[kid])))
+        assert fresh["numiters"] == committed[kid]["numiters"] and fresh["status"] == "Optimal"
+        assert len(fresh["iterations"]) == len(committed[kid]["iterations"])
+        for a, b in zip(fresh["iterations"], committed[kid]["iterations"]):
+            assert np.allclose(a["x"], b["x"], rtol=0, atol=1e-12) and a["nl_rows"] == b["nl_rows"]
+            assert [c["row"] for c in a["cuts"]] == [c["row"] for c in b["cuts"]]
+            for ca, cb in zip(a["cuts"], b["cuts"]):
+                assert np.allclose(ca["coefs"], cb["coefs"], rtol=1e-12, atol=1e-12)
