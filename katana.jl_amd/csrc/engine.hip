@@ -171,6 +171,7 @@ struct Engine {
     DBuf<double2> d_bpp;
     DBuf<int64_t> d_bseg;
     DBuf<int4> d_bkind;
+    DBuf<SepSlot> d_slots;
     DBuf<SepPartial> d_part;
     DBuf<double> d_rconst, d_lb, d_ub, d_nodec, d_nodeval, d_nodeadj;
     DBuf<int32_t> d_nlrows, d_allrows, d_taperows_all, d_taperows_nl;
@@ -395,7 +396,7 @@ struct Engine {
                 default: KTN_BLK_LAUNCH(8, 8192, 512, 4); break;
             }
 #undef KTN_BLK_LAUNCH
-            hipExtLaunchKernelGGL(k_sep_combine, dim3(ceil_div(m_nl, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, P, d_nlrows.p, m_nl, blk_nb,
+            hipExtLaunchKernelGGL(k_sep_combine, dim3(ceil_div(m_nl, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, d_slots.p, m_nl, blk_nb,
                                   d_part.p, f_tol, O);
         } else if (prm.profile) {
             const size_t ea = ev_get(), eb = ev_get();
@@ -688,7 +689,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
             for (int64_t e = h_rowptr[r] + 1; e < h_rowptr[r + 1]; ++e)
                 if (h_col[e] < h_col[e - 1]) { blk_on = false; break; }
         }
-        d_bcolk.release(); d_bpp.release(); d_bseg.release(); d_bkind.release(); d_part.release();
+        d_bcolk.release(); d_bpp.release(); d_bseg.release(); d_bkind.release(); d_part.release(); d_slots.release();
         if (blk_on) {
             std::vector<int64_t> bseg((size_t)(m_nl + 1) * blk_nb);
             std::vector<int4> bkind((size_t)(m_nl + 1) * blk_nb, make_int4(0, 0, 0, 0));
@@ -728,6 +729,16 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
             }
             d_bcolk.upload(bcolk.data(), (size_t)w, stream);
             d_bpp.upload(bpp.data(), (size_t)w, stream);
+            std::vector<SepSlot> slots((size_t)m_nl);
+            for (int64_t si = 0; si < m_nl; ++si) {
+                const int64_t r = h_nlrows[si];
+                SepSlot sl;
+                sl.rconst = rconst[r]; sl.lb = h_lb[r]; sl.ub = h_ub[r];
+                sl.row = (h_rowkind[r] == KTN_ROW_SEP) ? (int32_t)r : -1;
+                sl.len_pad = (int32_t)(((h_rowptr[r + 1] - h_rowptr[r]) << 1) | (padzero[r] ? 1 : 0));
+                slots[(size_t)si] = sl;
+            }
+            d_slots.upload(slots, stream);
             d_bseg.upload(bseg, stream);
             d_bkind.upload(bkind, stream);
             d_part.resize((size_t)m_nl * blk_nb, stream);

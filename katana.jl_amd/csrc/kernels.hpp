@@ -264,15 +264,19 @@ __global__ __launch_bounds__(BS) void k_sep_eval_blk(const int32_t* __restrict__
     }
 }
 
-// block-order combination of the partials + the isconstrsat tail of k_sep_eval
-__global__ __launch_bounds__(kBlock) void k_sep_combine(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl, int NB,
+// block-order combination of the partials + the isconstrsat tail of k_sep_eval.  Everything a slot needs sits in one
+// 32-byte record (no nl_rows -> row_kind -> bounds pointer chase: the kernel is 10 000 threads of pure latency).
+struct SepSlot { double rconst, lb, ub; int32_t row; int32_t len_pad; };   // len_pad = row length << 1 | pad_zero; row < 0: not separable
+
+__global__ __launch_bounds__(kBlock) void k_sep_combine(const SepSlot* __restrict__ slots, int64_t m_nl, int NB,
                                                         const SepPartial* __restrict__ part, double f_tol, SweepOut O) {
     const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (s >= m_nl) return;
-    const int32_t r = nl_rows[s];
-    if (P.row_kind[r] != KTN_ROW_SEP) return;
+    const SepSlot sl = slots[s];
+    if (sl.row < 0) return;
     double acc_g = 0.0, acc_dot = 0.0, mx = -__builtin_inf();
     int nf = 0;
+#pragma unroll 8
     for (int b = 0; b < NB; ++b) {
         const SepPartial q = part[(int64_t)b * m_nl + s];
         acc_g += q.g;
@@ -280,18 +284,18 @@ __global__ __launch_bounds__(kBlock) void k_sep_combine(NlpDev P, const int32_t*
         mx = nanmax(mx, q.mx);
         nf |= (q.nf != 0.0);
     }
-    const double g = acc_g + P.rconst[r];
-    if (P.pad_zero[r]) mx = nanmax(mx, 0.0);
+    const int32_t r = sl.row;
+    const double g = acc_g + sl.rconst;
+    if (sl.len_pad & 1) mx = nanmax(mx, 0.0);
     O.g[r] = g;
     O.bconst[r] = g - acc_dot;
     O.maxc[r] = mx;
     O.nonfin[r] = nf;
-    const double lb = P.lb[r], ub = P.ub[r];
-    const bool sat = (g >= lb - f_tol) && (g <= ub + f_tol);   // separators.jl:120 (NaN -> violated)
+    const bool sat = (g >= sl.lb - f_tol) && (g <= sl.ub + f_tol);   // separators.jl:120 (NaN -> violated)
     O.flag[s] = sat ? 0 : 1;
-    O.cnt[s] = sat ? 0 : (P.rowptr[r + 1] - P.rowptr[r]);
+    O.cnt[s] = sat ? 0 : (int64_t)(sl.len_pad >> 1);
     if (!sat) {
-        atomic_max_nonneg(O.maxviol, fmax(g - ub, lb - g));
+        atomic_max_nonneg(O.maxviol, fmax(g - sl.ub, sl.lb - g));
         if (nf) atomicOr(O.any_nonfin, 1);
     }
 }
