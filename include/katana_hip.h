@@ -109,7 +109,7 @@ typedef struct {
                                        problems (optimum on a curved face, e.g. test/2d.jl 107_01) dropping
                                        idle cuts makes Kelley's method cycle, so small pools are never purged */
     /* exact small-LP kernel (LPs of at most 32 columns; csrc/dense_lp.hpp) */
-    int32_t lp_dense_after; /* 20000   when the first-order LP has not converged after this many iterations the
+    int32_t lp_dense_after; /* 5000    when the first-order LP has not converged after this many iterations the
                                        LP is solved exactly by a dual active-set kernel (what the reference's
                                        simplex does on its small test models); 0 = never, < 0 = always exact */
 } ktn_params;

@@ -1526,7 +1526,7 @@ void ktn_default_params(ktn_params* p) {
     p->lp_tol_scale = 0.1; p->lp_tol_floor = 0.3; p->lp_tol_cap = 0.1; p->lp_gap_floor = 1e-7; p->lp_gap_cap = 1e-2;
     p->lp_dual_inherit = 1; p->profile = 0;
     p->purge_age = 2; p->purge_margin = 1e-3; p->purge_min_frac = 0.05; p->purge_min_rows = 2000;
-    p->lp_dense_after = 20000;
+    p->lp_dense_after = 5000;
 }
 
 int ktn_create(const ktn_params* p, ktn_handle* out) {

@@ -9,7 +9,7 @@ ids = sys.argv[1:]
 for k in load_kats():
     if ids != ["all"] and k["id"] not in ids:
         continue
-    M = hip_model_from_kat(ktn, k, lp_max_iter=int(os.environ.get("LPMAX", "2000000")))
+    M = hip_model_from_kat(ktn, k, lp_max_iter=int(os.environ.get("LPMAX", "2000000")), **({"lp_dense_after": int(os.environ["LPDENSE"])} if "LPDENSE" in os.environ else {}))
     t0 = time.time()
     st = M.solve()
     im = M.internal_model

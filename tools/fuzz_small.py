@@ -46,7 +46,7 @@ for t in range(N):
     if m["sense"] == "Max":
         m["sense"] = "Min"; m["objective"] = ["neg", m["objective"]]
     om = oracle_solve_kat(m)
-    M = hip_model_from_kat(ktn, m, lp_max_iter=MAXIT)
+    M = hip_model_from_kat(ktn, m, lp_max_iter=MAXIT, **({"lp_dense_after": int(os.environ["LPDENSE"])} if "LPDENSE" in os.environ else {}))
     t0 = time.time(); st = M.solve(); w = time.time() - t0
     so = om.getstatus()
     ok = (st == so) and (st != "Optimal" or abs(M.getobjectivevalue() - om.getobjval()) <= 1e-5 * max(1, abs(om.getobjval())))
