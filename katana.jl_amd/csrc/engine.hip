@@ -162,6 +162,7 @@ struct Engine {
     DBuf<int64_t> d_rowptr, d_nodeptr;
     DBuf<int32_t> d_col, d_nodeop, d_nodea, d_nodeb;
     DBuf<uint8_t> d_rowkind, d_padzero;
+    DBuf<uint64_t> d_dkeys, d_dsorted;      // deepest-cut selection
     DBuf<int32_t> d_colk;
     DBuf<double2> d_pp;
     // block-major copy of the long rows for the column-blocked sweep (k_sep_eval_blk)
@@ -423,9 +424,34 @@ struct Engine {
         KTN_HIP(hipMemcpyAsync(&anynf, d_anynf.p, 4, hipMemcpyDeviceToHost, stream));
         sync();
         if (prm.profile) ev_flush();
-        const int64_t V = tail[0] + tail[1], nnzV = tail[2] + tail[3];
-        *nviol_out = V;
+        int64_t V = tail[0] + tail[1], nnzV = tail[2] + tail[3];
+        *nviol_out = V;                // the stop rule counts EVERY violated row (model.jl:273-283)
         *maxviol_out = mv;
+        // Deepest-cut selection: an LP vertex is supported by at most n_lp rows, so when far more rows than that are
+        // violated only the cut_cap_factor * n_lp deepest get a cut this iteration (the reference cuts every violated
+        // row; with 1e6 NL rows over 1e5 variables that makes the LP 10x larger than it needs to be).  Ties at the
+        // threshold are all kept.  Never triggers on the reference's own test models.
+        const int64_t cap = (prm.cut_cap_factor > 0.0) ? std::max<int64_t>((int64_t)(prm.cut_cap_factor * (double)n_lp), prm.cut_cap_min) : 0;
+        if (cap > 0 && V > cap && !anynf) {
+            d_dkeys.resize((size_t)m_nl, stream); d_dsorted.resize((size_t)m_nl, stream);
+            LAUNCH_1(k_depth_keys, m_nl, stream, P, d_nlrows.p, m_nl, d_g.p, d_flag.p, d_dkeys.p);
+            const size_t need = sort_keys_desc_temp_bytes((size_t)m_nl);
+            d_sorttmp.resize(need + 16, stream);
+            KTN_HIP(sort_keys_desc_u64(d_sorttmp.p, need, d_dkeys.p, d_dsorted.p, (size_t)m_nl, stream));
+            LAUNCH_1(k_depth_reflag, m_nl, stream, m_nl, d_dkeys.p, d_dsorted.p, cap, d_flag.p, d_cnt.p);
+            check_launch();
+            exclusive_scan(d_flag.p, d_rank.p, (size_t)m_nl);
+            exclusive_scan(d_cnt.p, d_cntscan.p, (size_t)m_nl);
+            KTN_HIP(hipMemcpyAsync(&tail[0], d_flag.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
+            KTN_HIP(hipMemcpyAsync(&tail[1], d_rank.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
+            KTN_HIP(hipMemcpyAsync(&tail[2], d_cnt.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
+            KTN_HIP(hipMemcpyAsync(&tail[3], d_cntscan.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
+            sync();
+            V = tail[0] + tail[1];
+            nnzV = tail[2] + tail[3];
+            stats["cut_selections"] += 1.0;
+            stats["cuts_skipped"] += (double)(*nviol_out - V);
+        }
         if (anynf) {   // model.jl:69-73: "Nonlinear constraint or objective likely undefined within domain"
             *nonfinite_out = true;
             return;
@@ -888,7 +914,9 @@ void Engine::rebuild_csc() {
         while (((int64_t)1 << bits) < n_lp + 1 && bits < 31) ++bits;
         size_t need = sort_pairs_temp_bytes((size_t)NNZ);
         d_sorttmp.resize(need + 16, stream);
-        KTN_HIP(sort_pairs_u64_u32(d_sorttmp.p, need, k_in.p, k_out.p, p_in.p, p_out.p, (size_t)NNZ, 32 + bits, stream));
+        // keys are (col << 32 | row) in CSR order, i.e. already ascending in row: a STABLE sort on the column bits alone
+        // gives (col, row) order in 3 radix passes instead of 7
+        KTN_HIP(sort_pairs_u64_u32(d_sorttmp.p, need, k_in.p, k_out.p, p_in.p, p_out.p, (size_t)NNZ, 32, 32 + bits, stream));
         LAUNCH_1(k_csc_gather, NNZ, stream, NNZ, k_out.p, p_out.p, lp_val.p, c_row.p, c_val.p);
         check_launch();
     }
@@ -1090,8 +1118,18 @@ bool Engine::lp_solve_dense(LpResult* R) {
 LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identity_scaling) {
     auto t0 = std::chrono::steady_clock::now();
     LpResult R;
+    auto lap = [&](const char* key, std::chrono::steady_clock::time_point& tp) {     // setup breakdown (profile runs only)
+        if (!prm.profile) return;
+        sync();
+        const auto now = std::chrono::steady_clock::now();
+        stats[key] += std::chrono::duration<double>(now - tp).count();
+        tp = now;
+    };
+    auto tp = t0;
     if (lp_dirty) rebuild_csc();
+    lap("lp_csc_time_s", tp);
     compute_scaling(identity_scaling);
+    lap("lp_scaling_time_s", tp);
     const int64_t n = n_lp, m = M;
     const size_t mm = (size_t)std::max<int64_t>(m, 1);
     ch.resize(n, stream); lh.resize(n, stream); uh.resize(n, stream); xh.resize(n, stream);
@@ -1148,6 +1186,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         sync();
         smax = (nv2 > 0.0) ? std::sqrt(std::sqrt(nv2)) : 0.0;     // sigma_max^2 ~ ||A'A v||
     }
+    lap("lp_power_time_s", tp);
     const double fro = (NNZ > 0) ? std::sqrt(dev_dot(NNZ, r_sval.p, r_sval.p)) : 0.0;   // ||A||_2 <= ||A||_F
     if (!(smax > 0.0)) smax = fro;
     const double eta_safe = 0.998 / std::max(identity_scaling ? fro : std::min(1.0, fro), 1e-12);
@@ -1527,6 +1566,7 @@ void ktn_default_params(ktn_params* p) {
     p->lp_dual_inherit = 1; p->profile = 0;
     p->purge_age = 2; p->purge_margin = 1e-3; p->purge_min_frac = 0.05; p->purge_min_rows = 2000;
     p->lp_dense_after = 5000;
+    p->cut_cap_factor = 2.0; p->cut_cap_min = 10000;
 }
 
 int ktn_create(const ktn_params* p, ktn_handle* out) {

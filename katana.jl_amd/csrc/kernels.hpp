@@ -300,6 +300,32 @@ __global__ __launch_bounds__(kBlock) void k_sep_combine(const SepSlot* __restric
     }
 }
 
+// ---- deepest-cut selection (cut_cap): depth keys of the violated rows, then re-flagging against the threshold ----
+// key = bit pattern of the violation depth max(g - ub, lb - g) (non-negative doubles order like unsigned integers;
+// NaN counts as +inf), 0 for satisfied rows.
+__global__ __launch_bounds__(kBlock) void k_depth_keys(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
+                                                       const double* __restrict__ g, const int64_t* __restrict__ flag,
+                                                       uint64_t* __restrict__ keys) {
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= m_nl) return;
+    uint64_t k = 0;
+    if (flag[s]) {
+        const int32_t r = nl_rows[s];
+        double d = fmax(g[r] - P.ub[r], P.lb[r] - g[r]);
+        if (!(d == d)) d = __builtin_inf();
+        k = (d > 0.0) ? (uint64_t)__double_as_longlong(d) : 1ULL;     // violated within f_tol slack only: smallest key
+    }
+    keys[s] = k;
+}
+__global__ __launch_bounds__(kBlock) void k_depth_reflag(int64_t m_nl, const uint64_t* __restrict__ keys,
+                                                         const uint64_t* __restrict__ sorted_desc, int64_t keep,
+                                                         int64_t* __restrict__ flag, int64_t* __restrict__ cnt) {
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= m_nl) return;
+    const uint64_t thr = sorted_desc[keep - 1];
+    if (flag[s] && keys[s] < thr) { flag[s] = 0; cnt[s] = 0; }
+}
+
 // precompute! for tape rows: one thread per row, forward sweep then reverse sweep over
 // the row's expression DAG.  Derivative conventions follow the oracle (oracle/sexpr.py):
 // log' = 1/v, sqrt' = 0.5/sqrt(v), pow: 2 -> 2v, 1 -> 1, else p v^(p-1).

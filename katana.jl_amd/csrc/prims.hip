@@ -30,9 +30,21 @@ size_t sort_pairs_temp_bytes(size_t n) {
 }
 
 hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
-                              const uint32_t* vin, uint32_t* vout, size_t n, int end_bit,
+                              const uint32_t* vin, uint32_t* vout, size_t n, int begin_bit, int end_bit,
                               hipStream_t s) {
-    return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, 0, end_bit, s);
+    // LSD radix sort: stable, so sorting on a bit range keeps the input order among equal keys
+    return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s);
+}
+
+size_t sort_keys_desc_temp_bytes(size_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_keys_desc((void*)nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, n, 0, 64,
+                                        (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t sort_keys_desc_u64(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout, size_t n, hipStream_t s) {
+    return rocprim::radix_sort_keys_desc(temp, temp_bytes, kin, kout, n, 0, 64, s);
 }
 
 }  // namespace ktn

@@ -146,3 +146,42 @@ def test_fused_batch_mode_solves_every_instance():
         assert abs(r["objval"] - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
         assert max_nl_violation(inst, r["x"]) <= 1e-6 * (1 + 1e-6)
         assert np.max(np.abs(r["x"] - inst.xhat)) <= 1e-3
+
+
+def test_deepest_cut_selection_cuts_only_the_most_violated_rows():
+    """cut_cap_factor / cut_cap_min: when more NL rows are violated than an LP vertex can support, only the deepest get
+    a cut (src/model.jl:272-283 cuts them all); the rows chosen are exactly the top-K by violation depth"""
+    inst = ktn.instances.make_instance(n=400, m_nl=3000, k=12, family="explog", seed=21)
+    m = hip_load_instance(ktn, inst, cut_cap_factor=0.5, cut_cap_min=150)       # cap = max(0.5 * 400, 150) = 200
+    sep = ktn.KatanaHipSeparator(m); sep.initialize()
+    x = np.clip(inst.xhat + 0.9, inst.l_var, inst.u_var)
+    m0 = m.lp_num_rows()
+    sep.precompute(x)
+    nviol, maxviol = sep.sweep(1e-6)
+    g = sep.g[inst.m_lin:]
+    depth = np.maximum(g - inst.u_constr[inst.m_lin:], inst.l_constr[inst.m_lin:] - g)
+    violated = np.nonzero(depth > 1e-6)[0]
+    assert nviol == len(violated) > 200                       # the stop rule still sees every violated row
+    added = m.lp_num_rows() - m0
+    assert 200 <= added < len(violated) and m.stat("cut_selections") == 1
+    thr = np.sort(depth[violated])[::-1][199]
+    want = violated[depth[violated] >= thr]
+    assert added == len(want)
+    # each emitted cut is the tangent cut of one of the selected rows, in row order: compare the row bounds hi = ub - b
+    _, _, _, lo, hi = m.lp_rows_from(m0)
+    b = sep.g[inst.m_lin + want] - np.array([np.dot(x[inst.col[inst.rowptr[r]:inst.rowptr[r + 1]]],
+                                                    sep.jac[inst.rowptr[r]:inst.rowptr[r + 1]]) for r in inst.m_lin + want])
+    assert np.allclose(hi, inst.u_constr[inst.m_lin + want] - b, rtol=1e-10, atol=1e-10)
+
+
+def test_ecp_with_and_without_cut_selection_reach_the_same_optimum():
+    inst = ktn.instances.make_instance(n=300, m_nl=4000, k=10, family="explog", seed=22)
+    res = []
+    for kw in (dict(cut_cap_factor=0.0), dict(cut_cap_factor=1.0, cut_cap_min=100)):
+        m = hip_load_instance(ktn, inst, purge_age=0, **kw)
+        assert m.optimize() == "Optimal"
+        res.append((m.getobjval(), m.numcuts(), m.stat("cut_selections")))
+        assert max_nl_violation(inst, m.getsolution()) <= 1e-6 + 1e-9
+    assert res[0][2] == 0 and res[1][2] >= 1 and res[1][1] < res[0][1]
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * max(1.0, abs(res[0][0]))
+    assert abs(res[1][0] - inst.opt_obj) <= 1e-5 * max(1.0, abs(inst.opt_obj))

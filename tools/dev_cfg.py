@@ -5,7 +5,7 @@ import numpy as np
 import katana_jl_amd as ktn
 name = sys.argv[1]
 t = time.time(); inst = ktn.instances.make_config(name, seed=0); tg = time.time() - t
-m = ktn.NonlinearModel(ktn.KatanaSolver(log_level=1))
+m = ktn.NonlinearModel(ktn.KatanaSolver(log_level=1, **({"cut_cap_factor": float(os.environ["CUTCAP"])} if "CUTCAP" in os.environ else {})))
 t = time.time()
 m.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense, ktn.SeparableNLP(inst))
 tl = time.time() - t; t = time.time()
