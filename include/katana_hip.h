@@ -257,6 +257,9 @@ int64_t ktn_lp_nnz_from(ktn_handle h, int64_t first_row);
 int ktn_lp_get_rows_from(ktn_handle h, int64_t first_row, int64_t* rowptr, int32_t* col, double* val,
                          double* lo, double* hi);
 int ktn_lp_truncate(ktn_handle h, int64_t nrows);
+/* cut-pool purge after an LP solve (what ktn_ecp_step does between the LP and the sweep); deterministic, so ranks that
+ * hold identical LPs stay identical */
+int ktn_lp_purge(ktn_handle h, int64_t* rows_removed);
 int ktn_lp_append_rows(ktn_handle h, int64_t nrows, const int64_t* rowptr, const int32_t* col,
                        const double* val, const double* lo, const double* hi);
 

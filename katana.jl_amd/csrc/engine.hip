@@ -949,7 +949,14 @@ void Engine::purge_cuts() {
     LpRows New{lp_rowptr2.p, lp_col2.p, lp_val2.p, lp_lo2.p, lp_hi2.p, lp_y2.p};
     LAUNCH_1(k_purge_copy, m, stream, m, d_keep.p, d_newidx.p, d_newptr.p, Old, d_age.p, New, d_age2.p);
     KTN_HIP(hipMemcpyAsync(lp_rowptr2.p + m_new, &nnz_new, 8, hipMemcpyHostToDevice, stream));
-    LAUNCH_1(k_purge_relink, m_nl, stream, m_nl, d_lastcut.p, d_cutprev.p, d_keep.p, d_newidx.p, d_cutprev2.p);
+    if (!sharded_rows) {
+        LAUNCH_1(k_purge_relink, m_nl, stream, m_nl, d_lastcut.p, d_cutprev.p, d_keep.p, d_newidx.p, d_cutprev2.p);
+    } else {
+        // rows appended from the host (multi-GPU exchange) are not threaded into the per-row cut lists, and the
+        // lists are unused in that mode (no dual inheritance, no consolidation): void them
+        KTN_HIP(hipMemsetAsync(d_lastcut.p, 0xFF, d_lastcut.n * sizeof(int64_t), stream));
+        KTN_HIP(hipMemsetAsync(d_cutprev2.p, 0xFF, (size_t)m_new * sizeof(int64_t), stream));
+    }
     check_launch();
     sync();
     lp_rowptr.swap(lp_rowptr2); lp_col.swap(lp_col2); lp_val.swap(lp_val2); lp_lo.swap(lp_lo2); lp_hi.swap(lp_hi2);
@@ -1845,7 +1852,19 @@ int ktn_lp_truncate(ktn_handle h, int64_t nrows) {
         if (e->ds_valid.n) e->ds_valid.zero(e->stream);
         e->lp_rowptr.n = (size_t)nrows + 1; e->lp_col.n = e->lp_val.n = (size_t)base;
         e->lp_lo.n = e->lp_hi.n = e->lp_y.n = (size_t)nrows;
+        if (e->d_age.n > (size_t)nrows) e->d_age.n = (size_t)nrows;
+        if (e->d_cutprev.n > (size_t)nrows) e->d_cutprev.n = (size_t)nrows;
         e->lp_dirty = true;
+        return KTN_OK;
+    })
+}
+int ktn_lp_purge(ktn_handle h, int64_t* rows_removed) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded, "no problem loaded");
+        const int64_t before = e->M;
+        if (e->prm.purge_age > 0 && !e->prm.vis_data && e->M - e->M_base >= std::max<int64_t>(e->prm.purge_min_rows, 1)) e->purge_cuts();
+        if (rows_removed) *rows_removed = before - e->M;
         return KTN_OK;
     })
 }
@@ -1871,6 +1890,9 @@ int ktn_lp_append_rows(ktn_handle h, int64_t nrows, const int64_t* rowptr, const
         KTN_HIP(hipMemcpyAsync(e->lp_lo.p + e->M, lo, (size_t)nrows * 8, hipMemcpyHostToDevice, s));
         KTN_HIP(hipMemcpyAsync(e->lp_hi.p + e->M, hi, (size_t)nrows * 8, hipMemcpyHostToDevice, s));
         KTN_HIP(hipMemsetAsync(e->lp_y.p + e->M, 0, (size_t)nrows * 8, s));
+        e->d_age.resize((size_t)(e->M + nrows), s); e->d_cutprev.resize((size_t)(e->M + nrows), s);
+        KTN_HIP(hipMemsetAsync(e->d_age.p + e->M, 0, (size_t)nrows * sizeof(int32_t), s));
+        KTN_HIP(hipMemsetAsync(e->d_cutprev.p + e->M, 0xFF, (size_t)nrows * sizeof(int64_t), s));
         if (nz > 0) {
             KTN_HIP(hipMemcpyAsync(e->lp_col.p + e->NNZ, col + rowptr[0], (size_t)nz * 4, hipMemcpyHostToDevice, s));
             KTN_HIP(hipMemcpyAsync(e->lp_val.p + e->NNZ, val + rowptr[0], (size_t)nz * 8, hipMemcpyHostToDevice, s));

@@ -90,6 +90,14 @@ class ShardedKatanaModel:
     def __init__(self, solver, inst, rank, world, dist=None, exchange_device=None):
         self.rank, self.world, self.dist = rank, world, dist
         solver.gpu_options = dict(solver.gpu_options, lp_dual_inherit=0)
+        if world > 1 and "cut_cap_factor" not in solver.gpu_options:
+            # deepest-cut selection works per shard: split the cap so that the gathered LP gets what one GPU would add
+            import ctypes as C
+            from . import _lib as L
+            dp = L.KtnParams()
+            L.lib().ktn_default_params(C.byref(dp))
+            solver.gpu_options["cut_cap_factor"] = dp.cut_cap_factor / world
+            solver.gpu_options.setdefault("cut_cap_min", max(1, dp.cut_cap_min // world))
         self.p = dict(solver.model_params)
         self.inst = inst
         self.local = shard_instance(inst, rank, world)
@@ -108,6 +116,7 @@ class ShardedKatanaModel:
     def _reset_state(self):
         self.iter, self.allsat, self._status, self.last_maxviol = 0, False, "None", 1e300
         self.exchanged_rows = 0
+        self.purged_rows = 0
 
     def reset(self):
         self.m.reset()
@@ -129,6 +138,7 @@ class ShardedKatanaModel:
         if lp_status != "Optimal":
             self._status = lp_status
             return True
+        self.purged_rows += self.m.lp_purge()                     # identical LPs => identical purge on every rank
         m0 = self.m.lp_num_rows()
         nv_local, mv_local = self.m.sweep_lp_point(f_tol)
         err_local = self.m.status() == "Error"

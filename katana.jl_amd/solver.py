@@ -187,6 +187,12 @@ class KatanaNonlinearModel:
     def lp_truncate(self, nrows):
         L.check(self._h, self._lib.ktn_lp_truncate(self._h, nrows))
 
+    def lp_purge(self):
+        """cut-pool purge between the LP solve and the sweep (as ktn_ecp_step does); returns the number of rows dropped"""
+        n = C.c_int64(0)
+        L.check(self._h, self._lib.ktn_lp_purge(self._h, C.byref(n)))
+        return int(n.value)
+
     def lp_append_rows(self, rowptr, col, val, lo, hi):
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
         nr = len(rowptr) - 1

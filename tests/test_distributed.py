@@ -113,16 +113,16 @@ def test_pack_unpack_roundtrip_with_empty_and_ragged_blocks():
         assert np.array_equal(got[3], lo) and np.array_equal(got[4], hi, equal_nan=True)
 
 
-def _worker_gpu(rank, world, port, out):
+def _worker_gpu(rank, world, port, out, inst_kw=None, solver_kw=None):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     import katana_jl_amd as ktn
     from katana_jl_amd.distributed import ShardedKatanaModel
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    inst = ktn.instances.make_instance(n=4000, m_nl=400, k=16, family="explog", seed=21)
-    m = ShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0), inst, rank, world, dist)
+    inst = ktn.instances.make_instance(**(inst_kw or dict(n=4000, m_nl=400, k=16, family="explog", seed=21)))
+    m = ShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0, **(solver_kw or dict(purge_age=0))), inst, rank, world, dist)
     st = m.optimize()
-    out[rank] = (st, m.getobjval(), m.numiters(), m.numcuts(), m.getsolution())
+    out[rank] = (st, m.getobjval(), m.numiters(), m.numcuts(), m.getsolution(), m.purged_rows, m.m.lp_num_rows())
     dist.destroy_process_group()
 
 
@@ -136,7 +136,7 @@ def test_two_rank_sharded_solve_matches_single_gpu():
     inst = ktn.instances.make_instance(n=4000, m_nl=400, k=16, family="explog", seed=21)
     single = hip_load_instance(ktn, inst, lp_dual_inherit=0, purge_age=0)
     assert single.optimize() == "Optimal"
-    (s0, o0, it0, c0, x0), (s1, o1, it1, c1, x1) = out[0], out[1]
+    (s0, o0, it0, c0, x0, *_), (s1, o1, it1, c1, x1, *_) = out[0], out[1]
     assert s0 == s1 == "Optimal"
     assert o0 == o1 and it0 == it1 and c0 == c1 and np.array_equal(x0, x1)     # replicated LP: identical ranks
     # rank-ordered contiguous blocks == single-process row order => the very same trajectory
@@ -154,5 +154,39 @@ def test_sharded_model_world1_equals_engine_loop():
     a = ShardedKatanaModel(ktn.KatanaSolver(log_level=0), inst, 0, 1, None)
     assert a.optimize() == "Optimal"
     b = hip_load_instance(ktn, inst, lp_dual_inherit=0, purge_age=0)
+    assert b.optimize() == "Optimal"
+    assert a.getobjval() == b.getobjval() and a.numiters() == b.numiters() and a.numcuts() == b.numcuts()
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_solve_with_purging_and_cut_selection():
+    """the sharded loop purges idle cuts (ktn_lp_purge) and splits the deepest-cut cap over the ranks; the replicated
+    LPs stay identical and the solve ends at the planted optimum"""
+    import katana_jl_amd as ktn
+    from helpers import max_nl_violation
+    world = 2
+    inst_kw = dict(n=600, m_nl=6000, k=10, family="explog", seed=23)
+    solver_kw = dict(purge_age=2, purge_min_rows=300, cut_cap_factor=1.0, cut_cap_min=200)
+    out = mp.Manager().dict()
+    mp.spawn(_worker_gpu, args=(world, _free_port(), out, inst_kw, solver_kw), nprocs=world, join=True)
+    inst = ktn.instances.make_instance(**inst_kw)
+    (s0, o0, it0, c0, x0, p0, r0), (s1, o1, it1, c1, x1, p1, r1) = out[0], out[1]
+    assert s0 == s1 == "Optimal"
+    assert o0 == o1 and it0 == it1 and c0 == c1 and p0 == p1 and r0 == r1 and np.array_equal(x0, x1)
+    assert p0 > 0 and c0 < it0 * inst.m_nl                    # rows were purged; not every violated row was cut
+    assert abs(o0 - inst.opt_obj) <= 1e-5 * max(1, abs(inst.opt_obj))
+    assert max_nl_violation(inst, x0) <= 1e-6 * (1 + 1e-6)
+
+
+@pytest.mark.gpu
+def test_sharded_world1_with_purging_equals_engine_loop():
+    import katana_jl_amd as ktn
+    from helpers import hip_load_instance
+    from katana_jl_amd.distributed import ShardedKatanaModel
+    inst = ktn.instances.make_instance(n=600, m_nl=6000, k=10, family="explog", seed=23)
+    kw = dict(purge_age=2, purge_min_rows=300, cut_cap_factor=1.0, cut_cap_min=200)
+    a = ShardedKatanaModel(ktn.KatanaSolver(log_level=0, **kw), inst, 0, 1, None)
+    assert a.optimize() == "Optimal" and a.purged_rows > 0
+    b = hip_load_instance(ktn, inst, lp_dual_inherit=0, **kw)
     assert b.optimize() == "Optimal"
     assert a.getobjval() == b.getobjval() and a.numiters() == b.numiters() and a.numcuts() == b.numcuts()
