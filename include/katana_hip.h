@@ -33,6 +33,7 @@ extern "C" {
 #define KTN_E_NOMEM      -4
 #define KTN_E_UNSUPPORTED -5  /* e.g. unknown tape opcode ("Unsupported feature",
                                  src/nlpeval.jl:28)                                  */
+#define KTN_E_CALLBACK   -6   /* the caller's evaluator callback reported a failure  */
 
 /* ---- status vocabulary: MathProgBase.status(m) symbols ------------------------
  * :None src/model.jl:44, :Optimal, :Unbounded :246, LP pass-through e.g. :Infeasible
@@ -52,6 +53,17 @@ extern "C" {
  * eval_grad_f (call sites src/separators.jl:112-113, src/nlpeval.jl:35-63). */
 #define KTN_ROW_SEP  0   /* separable: g_i(x) = sum_e atom_e(x[col_e]) + rconst_i    */
 #define KTN_ROW_TAPE 1   /* general: postfix expression tape, reverse-mode AD        */
+#define KTN_ROW_HOST 2   /* fallback for evaluators that cannot hand over expressions (no :ExprGraph): values and
+                            derivatives come from the caller's own eval_g / eval_jac_g / eval_f / eval_grad_f through
+                            the callbacks below, once per sweep; isconstrsat, gencut, round_coefs, _addcut and the LP
+                            still run on the device (SURVEY.md section 8b "Evaluator consumed")                     */
+
+/* MathProgBase.eval_g + eval_jac_g (src/separators.jl:112-113) for the KTN_ROW_HOST rows: write g[i] and
+ * jac[rowptr[i] .. rowptr[i+1]) (CSR order of ktn_nlp_desc) for every such row i; other entries are ignored.
+ * x has num_var entries.  Return 0, or non-zero to make the running ktn_* call fail with KTN_E_CALLBACK. */
+typedef int (*ktn_eval_rows_cb)(void* user, const double* x, double* g, double* jac);
+/* MathProgBase.eval_f + eval_grad_f (src/nlpeval.jl:35-41) for a KTN_ROW_HOST objective: *f and the dense grad[num_var] */
+typedef int (*ktn_eval_obj_cb)(void* user, const double* x, double* f, double* grad);
 
 /* separable atoms, two f64 parameters per Jacobian entry */
 #define KTN_ATOM_LIN    0   /* p0 * x                */
@@ -143,7 +155,7 @@ typedef struct {
     const double*  tape_arg;
     /* objective f(x): isobjlinear src/model.jl:125; same two forms                  */
     int32_t obj_linear;
-    int32_t obj_kind;           /* KTN_ROW_SEP or KTN_ROW_TAPE                       */
+    int32_t obj_kind;           /* KTN_ROW_SEP, KTN_ROW_TAPE or KTN_ROW_HOST         */
     int64_t obj_nnz;            /* separable objective entries                       */
     const int32_t* obj_col;
     const uint8_t* obj_atom_kind;
@@ -153,6 +165,11 @@ typedef struct {
     int64_t        obj_tape_len;
     const int32_t* obj_tape_op;
     const double*  obj_tape_arg;
+    /* host-evaluator fallback (KTN_ROW_HOST rows / objective); NULL when unused.  Called on the thread that is
+     * inside ktn_loadproblem / ktn_optimize / ktn_ecp_step / ktn_sep_precompute / ktn_sep_sweep.            */
+    ktn_eval_rows_cb eval_rows;
+    ktn_eval_obj_cb  eval_obj;
+    void*            eval_user;
 } ktn_nlp_desc;
 
 /* ---- plugin surface -------------------------------------------------------------- */

@@ -15,7 +15,7 @@ a model without one raises.
 """
 from . import _lib
 from .expr import Expr, var, const, exp, log, sqrt, sin, cos, from_sexpr
-from .nlp import NLPDescription, SeparableNLP, ExprNLP
+from .nlp import NLPDescription, SeparableNLP, ExprNLP, CallbackNLP
 from .solver import (KatanaSolver, KatanaNonlinearModel, KatanaHipSeparator, NonlinearModel,
                      getKatanaModel, getKatanaCuts, getKatanaSols, STATUS_SYMBOLS)
 from .jump_like import Model
@@ -23,5 +23,5 @@ from . import instances
 from .batch import solve_batch
 
 __all__ = ["KatanaSolver", "KatanaNonlinearModel", "KatanaHipSeparator", "NonlinearModel", "getKatanaModel",
-           "getKatanaCuts", "getKatanaSols", "NLPDescription", "SeparableNLP", "ExprNLP", "Model", "Expr", "var",
+           "getKatanaCuts", "getKatanaSols", "NLPDescription", "SeparableNLP", "ExprNLP", "CallbackNLP", "Model", "Expr", "var",
            "const", "exp", "log", "sqrt", "sin", "cos", "from_sexpr", "instances", "STATUS_SYMBOLS", "solve_batch"]

@@ -9,7 +9,7 @@ KTN_OK = 0
 E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5
 STATUS_NONE, STATUS_OPTIMAL, STATUS_UNBOUNDED, STATUS_INFEASIBLE, STATUS_USERLIMIT, STATUS_ERROR = range(6)
 MIN, MAX = 0, 1
-ROW_SEP, ROW_TAPE = 0, 1
+ROW_SEP, ROW_TAPE, ROW_HOST = 0, 1, 2
 ATOM_LIN, ATOM_QUAD, ATOM_EXP, ATOM_NEGLOG = 0, 1, 2, 3
 (OP_CONST, OP_VAR, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_POWC, OP_EXP, OP_LOG, OP_SQRT, OP_SIN,
  OP_COS) = range(13)
@@ -33,7 +33,13 @@ class KtnNlpDesc(C.Structure):
                 ("p0", P(c_f64)), ("p1", P(c_f64)), ("tape_ptr", P(c_i64)), ("tape_op", P(c_i32)),
                 ("tape_arg", P(c_f64)), ("obj_linear", c_i32), ("obj_kind", c_i32), ("obj_nnz", c_i64),
                 ("obj_col", P(c_i32)), ("obj_atom_kind", P(c_u8)), ("obj_p0", P(c_f64)), ("obj_p1", P(c_f64)),
-                ("obj_const", c_f64), ("obj_tape_len", c_i64), ("obj_tape_op", P(c_i32)), ("obj_tape_arg", P(c_f64))]
+                ("obj_const", c_f64), ("obj_tape_len", c_i64), ("obj_tape_op", P(c_i32)), ("obj_tape_arg", P(c_f64)),
+                ("eval_rows", C.c_void_p), ("eval_obj", C.c_void_p), ("eval_user", C.c_void_p)]
+
+
+# ktn_eval_rows_cb / ktn_eval_obj_cb (include/katana_hip.h)
+EVAL_ROWS_CB = C.CFUNCTYPE(c_i32, C.c_void_p, P(c_f64), P(c_f64), P(c_f64))
+EVAL_OBJ_CB = C.CFUNCTYPE(c_i32, C.c_void_p, P(c_f64), P(c_f64), P(c_f64))
 
 
 # name -> (restype, argtypes); every function declared in include/katana_hip.h

@@ -163,6 +163,16 @@ struct Engine {
     DBuf<int32_t> d_col, d_nodeop, d_nodea, d_nodeb;
     DBuf<uint8_t> d_rowkind, d_padzero;
     DBuf<uint64_t> d_dkeys, d_dsorted;      // deepest-cut selection
+    // host-evaluator fallback (KTN_ROW_HOST)
+    ktn_eval_rows_cb cb_rows = nullptr;
+    ktn_eval_obj_cb cb_obj = nullptr;
+    void* cb_user = nullptr;
+    int64_t n_host = 0, n_host_nl = 0;
+    bool host_constr_rows = false, host_obj = false;
+    std::vector<double> h_xh, h_gh, h_jh;
+    DBuf<double> d_gh, d_jh;
+    DBuf<int32_t> d_hostrows;
+    void host_eval(const double* d_x);
     DBuf<int32_t> d_colk;
     DBuf<double2> d_pp;
     // block-major copy of the long rows for the column-blocked sweep (k_sep_eval_blk)
@@ -361,6 +371,7 @@ struct Engine {
         SweepOut O = sweep_view();
         LAUNCH_G(grp_sweep, k_sep_eval, m_ext, stream, P, d_allrows.p, m_ext, d_x, 0.0, 1, 0, O);
         LAUNCH_1(k_tape_eval, (int64_t)d_taperows_all.n, stream, P, d_taperows_all.p, (int64_t)d_taperows_all.n, d_x, O);
+        if (n_host > 0) host_eval(d_x);
         // cut constants / maxima of tape rows from the materialised Jacobian (flags unused here)
         KTN_HIP(hipMemsetAsync(d_scal.p, 0, sizeof(double), stream));
         KTN_HIP(hipMemsetAsync(d_anynf.p, 0, sizeof(int32_t), stream));
@@ -406,8 +417,9 @@ struct Engine {
         } else {
             LAUNCH_G(grp_sweep, k_sep_eval, m_nl, stream, P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O);
         }
-        if (n_tape_nl > 0) {
+        if (n_tape_nl > 0 || n_host_nl > 0) {
             LAUNCH_1(k_tape_eval, n_tape_nl, stream, P, d_taperows_nl.p, n_tape_nl, d_x, O);
+            if (n_host_nl > 0) host_eval(d_x);
             LAUNCH_1(k_gj_stats, m_nl, stream, P, d_nlrows.p, m_nl, d_x, f_tol, (int)KTN_ROW_TAPE, O);
         }
         check_launch();
@@ -547,6 +559,34 @@ static void postfix_to_nodes(const int32_t* op, const double* arg, int64_t len, 
     if (len > 0 && st.size() != 1) throw Error(KTN_E_INVALID, "malformed tape (stack not reduced to one value)");
 }
 
+// KTN_ROW_HOST: the caller's evaluator computes g and J of those rows at x (one call per sweep, like the reference's
+// precompute!, src/separators.jl:111-116); the values are staged to the device, everything downstream is unchanged.
+void Engine::host_eval(const double* d_x) {
+    const int64_t nx = std::min<int64_t>(n_lp > 0 ? n_lp : n0, n0 + 1);
+    KTN_HIP(hipMemcpyAsync(h_xh.data(), d_x, (size_t)nx * sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    if (host_constr_rows) {
+        const int rc = cb_rows(cb_user, h_xh.data(), h_gh.data(), h_jh.data());
+        if (rc != 0) throw Error(KTN_E_CALLBACK, "eval_rows callback failed (" + std::to_string(rc) + ")");
+    }
+    if (host_obj) {
+        double f = 0.0;
+        double* grad = h_jh.data() + h_rowptr[m0];
+        const int rc = cb_obj(cb_user, h_xh.data(), &f, grad);
+        if (rc != 0) throw Error(KTN_E_CALLBACK, "eval_obj callback failed (" + std::to_string(rc) + ")");
+        const double t = (nx > n0) ? h_xh[(size_t)n0] : 0.0;
+        h_gh[(size_t)m0] = f - t;                       // f(x) - t, src/nlpeval.jl:45
+        grad[n0] = -1.0;                                // src/nlpeval.jl:62
+    }
+    d_gh.upload(h_gh.data(), (size_t)m_ext, stream);
+    d_jh.upload(h_jh.data(), (size_t)nnz_ext, stream);
+    NlpDev P = nlp_view();
+    SweepOut O = sweep_view();
+    LAUNCH_1(k_host_scatter, n_host, stream, P, d_hostrows.p, n_host, d_gh.p, d_jh.p, O);
+    check_launch();
+    stats["host_evals"] += 1.0;
+}
+
 void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_var, const double* u_var,
                          const double* l_constr, const double* u_constr, int32_t sense_, const ktn_nlp_desc* d) {
     KTN_REQUIRE(d != nullptr, "nlp description is NULL");
@@ -594,6 +634,12 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
         p1.push_back(0.0);
         rconst[m0] = d->obj_const;
         h_rowkind[m0] = KTN_ROW_SEP;
+    } else if (d->obj_kind == KTN_ROW_HOST) {
+        // dense row, like the reference's own epigraph row (src/nlpeval.jl:49-54)
+        KTN_REQUIRE(d->eval_obj != nullptr, "KTN_ROW_HOST objective without eval_obj callback");
+        for (int64_t j = 0; j <= n0; ++j) { h_col.push_back((int32_t)j); akind.push_back(0); p0.push_back(0.0); p1.push_back(0.0); }
+        rconst[m0] = 0.0;
+        h_rowkind[m0] = KTN_ROW_HOST;
     } else {
         for (int64_t t = 0; t < d->obj_tape_len; ++t)
             if (d->obj_tape_op[t] == KTN_OP_VAR) ocols.push_back((int32_t)d->obj_tape_arg[t]);
@@ -610,6 +656,26 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     h_rowptr.push_back((int64_t)h_col.size());
     nnz_ext = (int64_t)h_col.size();
     padzero[m0] = (h_rowptr[m0 + 1] - h_rowptr[m0]) < (n0 + 1) ? 1 : 0;
+
+    // ---- host-evaluated rows
+    cb_rows = d->eval_rows; cb_obj = d->eval_obj; cb_user = d->eval_user;
+    host_obj = h_rowkind[m0] == KTN_ROW_HOST;
+    host_constr_rows = false;
+    {
+        std::vector<int32_t> hostrows;
+        for (int64_t i = 0; i < m_ext; ++i) {
+            KTN_REQUIRE(h_rowkind[i] <= KTN_ROW_HOST, "unknown row kind");
+            if (h_rowkind[i] != KTN_ROW_HOST) continue;
+            hostrows.push_back((int32_t)i);
+            if (i < m0) host_constr_rows = true;
+        }
+        KTN_REQUIRE(!host_constr_rows || cb_rows != nullptr, "KTN_ROW_HOST rows without eval_rows callback");
+        n_host = (int64_t)hostrows.size();
+        d_hostrows.upload(hostrows, stream);
+        h_gh.assign((size_t)m_ext, 0.0);
+        h_jh.assign((size_t)nnz_ext + 1, 0.0);
+        h_xh.assign((size_t)n0 + 1, 0.0);
+    }
 
     // ---- tapes -> expression DAGs
     std::vector<int64_t> nodeptr(m_ext + 1, 0);
@@ -692,6 +758,8 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
         nnz_nl += h_rowptr[r + 1] - h_rowptr[r];
     }
     n_tape_nl = (int64_t)tape_nl.size();
+    n_host_nl = 0;
+    for (auto r : h_nlrows) n_host_nl += (h_rowkind[r] == KTN_ROW_HOST) ? 1 : 0;
     d_taperows_nl.upload(tape_nl, stream);
     d_nlrows.upload(h_nlrows, stream);
     grp_sweep = pick_group(m_nl ? (double)nnz_nl / (double)m_nl : 4.0);

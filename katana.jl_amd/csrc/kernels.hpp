@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_gj_stats(NlpDev P, const int32_t* __
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= m_nl) return;
     const int32_t r = nl_rows[gid];
-    if (kind_filter >= 0 && P.row_kind[r] != kind_filter) return;
+    if (kind_filter >= 0 && P.row_kind[r] == KTN_ROW_SEP) return;     // tape rows and host-evaluated rows
     const int64_t beg = P.rowptr[r], end = P.rowptr[r + 1];
     const double g = O.g[r];
     double b = g, mx = -__builtin_inf();
@@ -423,6 +423,16 @@ __global__ __launch_bounds__(kBlock) void k_gj_stats(NlpDev P, const int32_t* __
         atomic_max_nonneg(O.maxviol, fmax(g - ub, lb - g));
         if (nf) atomicOr(O.any_nonfin, 1);
     }
+}
+
+// KTN_ROW_HOST rows: values and Jacobian entries computed by the caller's evaluator, staged in (gh, jh)
+__global__ __launch_bounds__(kBlock) void k_host_scatter(NlpDev P, const int32_t* __restrict__ host_rows, int64_t n_host,
+                                                         const double* __restrict__ gh, const double* __restrict__ jh, SweepOut O) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n_host) return;
+    const int32_t r = host_rows[t];
+    O.g[r] = gh[r];
+    for (int64_t e = P.rowptr[r]; e < P.rowptr[r + 1]; ++e) O.jac[e] = jh[e];
 }
 
 // Growing row-sparse LP  lo <= A x <= hi  (CSR, rows only ever appended).

@@ -130,3 +130,66 @@ def ExprNLP(num_var, objective, constraints, constr_linear=None, obj_linear=None
         kw = dict(obj_kind=L.ROW_TAPE, obj_tape_op=o, obj_tape_arg=a)
     return NLPDescription(num_var, rowptr, col, rkind, rlin, rconst, akind, p0, p1, tptr, top, targ,
                           obj_linear=is_lin, **kw)
+
+
+class CallbackNLP(NLPDescription):
+    """The fallback for evaluators that cannot hand over expressions (SURVEY.md section 8b "Evaluator consumed"): wraps an
+    object with the MathProgBase.AbstractNLPEvaluator methods the reference calls -- `jac_structure()`,
+    `eval_g(g, x)`, `eval_jac_g(J, x)`, `eval_f(x)`, `eval_grad_f(grad, x)`, `isconstrlinear(i)`, `isobjlinear()`
+    (src/separators.jl:88-113, src/model.jl:116,125,159, src/nlpeval.jl:31-63) -- and declares every row KTN_ROW_HOST.
+    Values and derivatives are then computed by that object on the host, once per sweep; constraint checks, cuts and the
+    LP stay on the device.  The COO structure is converted to CSR exactly as initialize! does (src/separators.jl:92-104:
+    row by row, entries in COO order)."""
+
+    def __init__(self, evaluator, num_var, num_constr):
+        if hasattr(evaluator, "initialize"):
+            evaluator.initialize(["Grad", "Jac"])                      # src/separators.jl:88
+        rows, cols = evaluator.jac_structure()
+        rows = np.asarray(rows, dtype=np.int64); cols = np.asarray(cols, dtype=np.int64)
+        order = np.argsort(rows, kind="stable")
+        rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=num_constr))])
+        nnz = len(rows)
+        lin = [1 if evaluator.isconstrlinear(i) else 0 for i in range(num_constr)]
+        super().__init__(num_var, rowptr, cols[order], np.full(num_constr, L.ROW_HOST), lin, np.zeros(num_constr),
+                         None, None, None, obj_linear=bool(evaluator.isobjlinear()), obj_kind=L.ROW_HOST)
+        self.evaluator = evaluator
+        n, m = int(num_var), int(num_constr)
+
+        def rows_cb(_user, xp, gp, jp):
+            try:
+                x = np.ctypeslib.as_array(xp, (n,)).copy()
+                g = np.zeros(m); J = np.zeros(nnz)
+                with np.errstate(all="ignore"):
+                    evaluator.eval_g(g, x)                              # src/separators.jl:113
+                    evaluator.eval_jac_g(J, x)                          # src/separators.jl:112
+                if m:
+                    np.ctypeslib.as_array(gp, (m,))[:] = g
+                if nnz:
+                    np.ctypeslib.as_array(jp, (nnz,))[:] = J[order]
+                return 0
+            except Exception:                                           # never unwind through the C ABI
+                return 1
+
+        def obj_cb(_user, xp, fp, gradp):
+            try:
+                x = np.ctypeslib.as_array(xp, (n,)).copy()
+                grad = np.zeros(n)
+                with np.errstate(all="ignore"):
+                    f = evaluator.eval_f(x)                             # src/nlpeval.jl:35
+                    evaluator.eval_grad_f(grad, x)                      # src/nlpeval.jl:37-41
+                fp[0] = float(f)
+                if n:
+                    np.ctypeslib.as_array(gradp, (n,))[:] = grad
+                return 0
+            except Exception:
+                return 1
+
+        self._rows_cb = L.EVAL_ROWS_CB(rows_cb)       # keep the trampolines alive as long as the description
+        self._obj_cb = L.EVAL_OBJ_CB(obj_cb)
+
+    def c_struct(self):
+        d = super().c_struct()
+        d.eval_rows = C.cast(self._rows_cb, C.c_void_p)
+        d.eval_obj = C.cast(self._obj_cb, C.c_void_p)
+        d.eval_user = None
+        return d

@@ -103,3 +103,48 @@ def test_max_sense_with_nonlinear_objective():
     assert M.solve() == "Optimal"
     assert abs(M.getobjectivevalue() + 0.17157287525380990) < 1e-6        # -(sqrt(2)-1)^2
     assert np.allclose(M.getvalue(), [2 ** -0.5, 2 ** -0.5], atol=1e-3)
+
+
+# ---- host-evaluator fallback (KTN_ROW_HOST, SURVEY.md section 8b "Evaluator consumed") -------------------------------
+# A caller whose MathProgBase evaluator cannot hand over expressions passes callbacks instead; here the oracle's
+# evaluator plays that caller-side `d`.  Same expectations as the device-evaluated run above.
+HOST_IDS = ["basic_1", "basic_2", "001_01", "002_02", "101_01", "102_03", "103_04", "105_01", "105_04", "107_02", "108_01",
+            "110_02", "201_01", "202_03", "205_01", "210_02", "501_01_n1", "501_01_n7", "501_02_n12", "501_02_n20"]
+
+
+@pytest.mark.parametrize("m", [k for k in KATS if k["id"] in HOST_IDS], ids=lambda k: k["id"])
+def test_reference_kat_through_host_evaluator_callbacks(m):
+    from oracle.evaluators import SexprNLPEvaluator
+    n, mc = len(m["vars"]), len(m["constraints"])
+    user_d = SexprNLPEvaluator(n, m["objective"], [c["expr"] for c in m["constraints"]],
+                               [c["linear"] for c in m["constraints"]], m["objective_linear"])
+    im = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0))
+    im.loadproblem(n, mc, [v["lb"] for v in m["vars"]], [v["ub"] for v in m["vars"]],
+                   [c["lb"] for c in m["constraints"]], [c["ub"] for c in m["constraints"]], m["sense"],
+                   ktn.CallbackNLP(user_d, n, mc))
+    status = im.optimize()
+    e = m["expect"]
+    assert status == e["status"]
+    assert im.stat("host_evals") >= 1
+    otol = 5e-6 if m["id"] in FLAT else 1e-6
+    assert isapprox(im.getobjval(), e["obj"], otol, otol), (im.getobjval(), e["obj"])
+    if e["x"] is not None:
+        tol = 3e-3 if (m["id"] in FLAT or m["id"].startswith("501_02")) else e["sol_atol"]
+        for got, want in zip(im.getsolution()[:n], e["x"]):
+            assert isapprox(got, want, tol, tol)
+
+
+def test_failing_evaluator_callback_surfaces_as_an_error_code():
+    class Broken:
+        def initialize(self, req): pass
+        def jac_structure(self): return [0, 0], [0, 1]
+        def isconstrlinear(self, i): return False
+        def isobjlinear(self): return True
+        def eval_f(self, x): return float(x[0])
+        def eval_grad_f(self, g, x): g[:] = [1.0, 0.0]
+        def eval_g(self, g, x): raise RuntimeError("boom")
+        def eval_jac_g(self, J, x): J[:] = 0.0
+    im = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0))
+    with pytest.raises(ktn._lib.KatanaHipError) as ei:
+        im.loadproblem(2, 1, [-1.0, -1.0], [1.0, 1.0], [-np.inf], [1.0], "Min", ktn.CallbackNLP(Broken(), 2, 1))
+    assert "eval_rows callback failed" in str(ei.value)
