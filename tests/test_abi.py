@@ -78,3 +78,30 @@ def test_product_never_imports_the_oracle():
 def test_unknown_feature_and_option_are_errors(ktn):
     with pytest.raises(ValueError):
         ktn.KatanaSolver(features=["NoSuchFeature"])          # setfield! on KatanaFeatures, src/model.jl:50-52
+
+
+def _build_c_smoke(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ktn_c_smoke")
+    libdir = os.path.join(root, "katana.jl_amd")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c", "ktn_c_smoke.c"), "-o", exe, "-L" + libdir, "-lkatana_hip", "-lm",
+                    "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """include/katana_hip.h compiles as C11 (-Wall -Werror) and a C caller links; without a GPU ktn_create refuses (77)"""
+    import subprocess
+    r = subprocess.run([_build_c_smoke(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode in (0, 77), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_c_caller_solves_a_reference_model_through_the_abi(tmp_path):
+    """tests/c/ktn_c_smoke.c: test/2d.jl 101_01 from plain C -- no Python, no torch in the call path"""
+    import subprocess
+    r = subprocess.run([_build_c_smoke(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "status 1 objective -1.41421" in r.stdout
