@@ -185,3 +185,17 @@ def test_ecp_with_and_without_cut_selection_reach_the_same_optimum():
     assert res[0][2] == 0 and res[1][2] >= 1 and res[1][1] < res[0][1]
     assert abs(res[0][0] - res[1][0]) <= 2e-6 * max(1.0, abs(res[0][0]))
     assert abs(res[1][0] - inst.opt_obj) <= 1e-5 * max(1.0, abs(inst.opt_obj))
+
+
+def test_full_size_cfg4_one_million_nonlinear_rows():
+    """BASELINE.json configs[3] at full size on ONE GPU (n = 1e5, 1e6 exp/log rows, 3.2e7 Jacobian entries): planted optimum,
+    every one of the 1e6 rows within f_tol, purging and deepest-cut selection at work"""
+    inst = ktn.instances.make_config("cfg4", seed=0)
+    m = hip_load_instance(ktn, inst)
+    assert m.optimize() == "Optimal"
+    x = m.getsolution()
+    assert abs(m.getobjval() - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+    assert max_nl_violation(inst, x) <= 1e-6 * (1 + 1e-6)
+    assert np.max(np.abs(x - inst.xhat)) <= 1e-3
+    assert m.stat("cut_selections") >= 1 and m.stat("purged_rows") > 0
+    assert m.numcuts() < 3 * inst.m_nl and m.lp_num_rows() < inst.m_lin + inst.m_nl // 2
