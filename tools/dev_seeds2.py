@@ -1,0 +1,17 @@
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import katana_jl_amd as ktn
+name, n0, n1 = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+tot_w = tot_p = 0; ws = []
+for seed in range(n0, n1):
+    inst = ktn.instances.make_config(name, seed=seed)
+    m = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0))
+    m.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense, ktn.SeparableNLP(inst))
+    if seed == n0:
+        m.optimize(); m.reset()          # warm the process
+    t = time.time(); st = m.optimize(); w = time.time() - t
+    assert st == "Optimal"
+    ws.append(w); tot_p += m.stat("pdhg_iters")
+print("%s seeds %d-%d: mean %.3fs median %.3fs max %.3fs total pdhg %d | %s" % (name, n0, n1 - 1, np.mean(ws), np.median(ws), np.max(ws), tot_p, " ".join("%.3f" % w for w in ws)))
