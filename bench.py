@@ -222,6 +222,12 @@ def main():
                           "kernel": "k_sep_eval_blk + k_sep_combine (column-blocked separator sweep)",
                           "workload": "cfg3_hbm: n=%d, m_nl=%d exp/log rows, k=%d" % (hb.n, hb.m_nl, hb.meta["k"]),
                           "launches": int(dn), "avg_launch_us": 1e6 * dt / dn, "algorithmic_bytes_per_launch": db / dn}
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath)).get("k_sep_eval_blk")
+            if t:
+                sweep_roofline["traffic"] = t["bytes_per_launch"]
+                sweep_roofline["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction for 16-B/lane streams)"
         del sm, sep, hb
 
     cpu = None
