@@ -183,6 +183,10 @@ int ktn_create(const ktn_params* p, ktn_handle* out);
 void ktn_destroy(ktn_handle h);
 const char* ktn_last_error(ktn_handle h);
 int ktn_abi_version(void);
+/* sizeof(ktn_params) / sizeof(ktn_nlp_desc) as compiled into the library: a binding checks its own struct mirrors
+ * against these before the first call (a layout mismatch would otherwise corrupt memory silently) */
+int64_t ktn_sizeof_params(void);
+int64_t ktn_sizeof_nlp_desc(void);
 
 /* MathProgBase.loadproblem!(m, num_var, num_constr, l_var, u_var, l_constr, u_constr,
  * sense, d)  src/model.jl:81-173 */

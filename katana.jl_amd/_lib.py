@@ -45,6 +45,8 @@ EVAL_OBJ_CB = C.CFUNCTYPE(c_i32, C.c_void_p, P(c_f64), P(c_f64), P(c_f64))
 # name -> (restype, argtypes); every function declared in include/katana_hip.h
 PROTOTYPES = {
     "ktn_abi_version": (c_i32, []),
+    "ktn_sizeof_params": (c_i64, []),
+    "ktn_sizeof_nlp_desc": (c_i64, []),
     "ktn_default_params": (None, [P(KtnParams)]),
     "ktn_create": (c_i32, [P(KtnParams), P(C.c_void_p)]),
     "ktn_destroy": (None, [C.c_void_p]),
@@ -114,6 +116,10 @@ def lib():
             fn = getattr(L, name)      # AttributeError here == ABI symbol missing
             fn.restype = res
             fn.argtypes = args
+        if L.ktn_sizeof_params() != C.sizeof(KtnParams) or L.ktn_sizeof_nlp_desc() != C.sizeof(KtnNlpDesc):
+            raise RuntimeError("libkatana_hip.so was built from a different include/katana_hip.h than this binding mirrors "
+                               "(ktn_params %d vs %d bytes, ktn_nlp_desc %d vs %d): rebuild the library" % (
+                                   L.ktn_sizeof_params(), C.sizeof(KtnParams), L.ktn_sizeof_nlp_desc(), C.sizeof(KtnNlpDesc)))
         _lib = L
     return _lib
 

@@ -1631,6 +1631,8 @@ struct ktn_handle_s {
 extern "C" {
 
 int ktn_abi_version(void) { return KTN_ABI_VERSION; }
+int64_t ktn_sizeof_params(void) { return (int64_t)sizeof(ktn_params); }
+int64_t ktn_sizeof_nlp_desc(void) { return (int64_t)sizeof(ktn_nlp_desc); }
 
 void ktn_default_params(ktn_params* p) {
     if (!p) return;

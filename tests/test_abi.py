@@ -105,3 +105,15 @@ def test_c_caller_solves_a_reference_model_through_the_abi(tmp_path):
     r = subprocess.run([_build_c_smoke(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "status 1 objective -1.41421" in r.stdout
+
+
+def test_binding_structs_have_the_library_layout():
+    import ctypes as C
+    import katana_jl_amd as ktn
+    L = ktn._lib
+    assert L.lib().ktn_sizeof_params() == C.sizeof(L.KtnParams)
+    assert L.lib().ktn_sizeof_nlp_desc() == C.sizeof(L.KtnNlpDesc)
+    p = L.KtnParams()
+    L.lib().ktn_default_params(C.byref(p))
+    # the last fields of the struct read back their documented defaults: the mirror is aligned end to end
+    assert (p.f_tol, p.iter_cap, p.purge_min_rows, p.lp_dense_after, p.cut_cap_factor, p.cut_cap_min) == (1e-6, 10000, 2000, 5000, 2.0, 10000)
