@@ -67,6 +67,23 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "oracle/_ref" in txt:
                     bad.append(f)
     assert not bad, bad
+    # tools/ is development tooling outside tests/: it must not touch the oracle either (directly or through tests/helpers)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            txt = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+(oracle|helpers)\b", txt, flags=re.M), f
+    # bench.py: only inside cpu_baseline(); __graft_entry__.py: only inside smoke()
+    for fname, allowed in (("bench.py", "cpu_baseline"), ("__graft_entry__.py", "smoke")):
+        src = open(os.path.join(ROOT, fname)).read()
+        import ast
+        tree = ast.parse(src)
+        for node in ast.walk(tree):
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                names = [a.name for a in node.names] if isinstance(node, ast.Import) else [node.module or ""]
+                if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                    owner = [fn.name for fn in ast.walk(tree) if isinstance(fn, ast.FunctionDef)
+                             and fn.lineno <= node.lineno <= fn.end_lineno]
+                    assert allowed in owner, (fname, node.lineno, owner)
     # and importing the product in a clean interpreter pulls in neither oracle nor scipy's LP
     out = subprocess.run([sys.executable, "-c",
                           "import sys; sys.path.insert(0, %r); import katana_jl_amd; "

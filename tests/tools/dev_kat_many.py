@@ -1,6 +1,6 @@
 """dev: run a list of KAT ids (or 'all') on the GPU, one line each: status objective expected iters time stats."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import katana_jl_amd as ktn
 from kat_util import load_kats

@@ -1,6 +1,6 @@
 """Development aid: random small convex models (tape rows) -- HIP engine vs the CPU oracle."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import katana_jl_amd as ktn
