@@ -278,6 +278,15 @@ int64_t ktn_lp_nnz_from(ktn_handle h, int64_t first_row);
 int ktn_lp_get_rows_from(ktn_handle h, int64_t first_row, int64_t* rowptr, int32_t* col, double* val,
                          double* lo, double* hi);
 int ktn_lp_truncate(ktn_handle h, int64_t nrows);
+/* Per-NL-row cut lists across ranks: after ktn_lp_enable_global_lists(h, total NL rows of the unsharded problem) rows
+ * appended with ktn_lp_append_rows_nl carry the GLOBAL NL-row id of the row they cut (-1: none); the engine then gives them
+ * the bookkeeping its own sweep gives local cuts -- the new cut inherits the multiplier of the row's previous cut
+ * (lp_dual_inherit), stall consolidation and purging see the lists.  ktn_last_sweep_slots returns, for the cuts the last
+ * sweep appended, the local NL slot (0-based position among this handle's NL rows) of each, in row order. */
+int ktn_lp_enable_global_lists(ktn_handle h, int64_t nl_total);
+int ktn_last_sweep_slots(ktn_handle h, int64_t* slots, int64_t cap, int64_t* count);
+int ktn_lp_append_rows_nl(ktn_handle h, int64_t nrows, const int64_t* rowptr, const int32_t* col, const double* val,
+                          const double* lo, const double* hi, const int64_t* nl_id);
 /* cut-pool purge after an LP solve (what ktn_ecp_step does between the LP and the sweep); deterministic, so ranks that
  * hold identical LPs stay identical */
 int ktn_lp_purge(ktn_handle h, int64_t* rows_removed);

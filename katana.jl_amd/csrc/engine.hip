@@ -206,7 +206,19 @@ struct Engine {
     int64_t M = 0, NNZ = 0, M_base = 0, NNZ_base = 0;
     int64_t numcuts = 0, numcuts_base = 0;
     bool lp_dirty = true;
-    bool sharded_rows = false;   // rows were appended/truncated from the host: cut lists are not tracked
+    bool sharded_rows = false;   // rows were appended/truncated from the host: cut lists are not tracked ...
+    bool glists = false;         // ... unless the host supplies global NL-row ids (ktn_lp_enable_global_lists)
+    int64_t nl_total = 0;
+    int64_t last_sweep_cuts = 0;
+    DBuf<int64_t> d_glast, d_nlid;
+    void append_link(int64_t nrows, const int64_t* nl_id_host) {       // rows [M, M + nrows) just appended from the host
+        d_nlid.upload(nl_id_host, (size_t)nrows, stream);
+        LAUNCH_1(k_append_link, nrows, stream, nrows, M, d_nlid.p, nl_total, d_glast.p, d_cutprev.p, lp_y.p, (int)prm.lp_dual_inherit);
+        check_launch();
+    }
+    int64_t* list_heads() { return glists ? d_glast.p : d_lastcut.p; }
+    int64_t list_count() const { return glists ? nl_total : m_nl; }
+    bool lists_ok() const { return !sharded_rows || glists; }
     // CSC mirror + scaling + PDHG workspace
     DBuf<int64_t> c_ptr, c_cnt;
     DBuf<int32_t> c_row;
@@ -385,6 +397,7 @@ struct Engine {
         *nviol_out = 0;
         *maxviol_out = 0.0;
         *nonfinite_out = false;
+        last_sweep_cuts = 0;
         stats["sweeps"] += 1.0;
         if (m_nl == 0) return;
         NlpDev P = nlp_view();
@@ -481,13 +494,14 @@ struct Engine {
             d_violslots.resize((size_t)V, stream);
             LpRows L = lp_view();
             LAUNCH_1(k_compact, m_nl, stream, P, d_nlrows.p, m_nl, d_flag.p, d_rank.p, d_cntscan.p, d_bconst.p, M, NNZ, L,
-                     d_violslots.p, d_lastcut.p, d_cutprev.p, (int)prm.lp_dual_inherit);
+                     d_violslots.p, d_lastcut.p, d_cutprev.p, (int)(prm.lp_dual_inherit && !glists));
             LAUNCH_G(grp_sweep, k_emit, V, stream, P, d_nlrows.p, d_violslots.p, V, d_x, d_jac.p, d_maxc.p,
                      prm.cut_coef_rng, 1, M, L);
             check_launch();
             M += V;
             NNZ += nnzV;
             numcuts += V;
+            last_sweep_cuts = V;
             lp_dirty = true;
         }
         sync();
@@ -952,6 +966,8 @@ void Engine::reset() {
     lp_dirty = true; have_omega = false; have_precompute = false; sharded_rows = false;
     if (ds_valid.n) ds_valid.zero(stream);
     dense_credit = dense_run = 0;
+    if (glists) KTN_HIP(hipMemsetAsync(d_glast.p, 0xFF, d_glast.n * sizeof(int64_t), stream));
+    last_sweep_cuts = 0;
     power_v.n = 0;
     status = KTN_STATUS_NONE; lp_status = KTN_STATUS_OPTIMAL;
     iter = 0; soltime = 0.0; objval = std::numeric_limits<double>::quiet_NaN();
@@ -1017,8 +1033,8 @@ void Engine::purge_cuts() {
     LpRows New{lp_rowptr2.p, lp_col2.p, lp_val2.p, lp_lo2.p, lp_hi2.p, lp_y2.p};
     LAUNCH_1(k_purge_copy, m, stream, m, d_keep.p, d_newidx.p, d_newptr.p, Old, d_age.p, New, d_age2.p);
     KTN_HIP(hipMemcpyAsync(lp_rowptr2.p + m_new, &nnz_new, 8, hipMemcpyHostToDevice, stream));
-    if (!sharded_rows) {
-        LAUNCH_1(k_purge_relink, m_nl, stream, m_nl, d_lastcut.p, d_cutprev.p, d_keep.p, d_newidx.p, d_cutprev2.p);
+    if (lists_ok()) {
+        LAUNCH_1(k_purge_relink, list_count(), stream, list_count(), list_heads(), d_cutprev.p, d_keep.p, d_newidx.p, d_cutprev2.p);
     } else {
         // rows appended from the host (multi-GPU exchange) are not threaded into the per-row cut lists, and the
         // lists are unused in that mode (no dual inheritance, no consolidation): void them
@@ -1396,7 +1412,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         // objective converged, rows not, residual flat: PDHG is idling between near-parallel cuts of one
         // NL row (k_consolidate).  Move the multiplier mass onto the tightest cut at the current point and
         // restart from there.
-        if (mode == 0 && k > 0 && prm.lp_dual_inherit && !sharded_rows && m_nl > 0 && m > M_base && gap <= tol_g &&
+        if (mode == 0 && k > 0 && prm.lp_dual_inherit && lists_ok() && list_count() > 0 && m > M_base && gap <= tol_g &&
             dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2)) && pviol > tol_p) {
             flat_rows = (r_last_check > 0.0 && r > 0.98 * r_last_check) ? flat_rows + 1 : 0;
             if (flat_rows >= 3 && consolidations < 8) {
@@ -1407,7 +1423,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
                 SpMat Au{lp_rowptr.p, lp_col.p, lp_val.p};
                 LAUNCH_G(grp_rows, k_spmv, m, stream, m, Au, pv.p, pw.p);
                 KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
-                LAUNCH_1(k_consolidate, m_nl, stream, m_nl, d_lastcut.p, d_cutprev.p, pw.p, lp_lo.p, lp_hi.p, dr.p, tol_p, yth.p,
+                LAUNCH_1(k_consolidate, list_count(), stream, list_count(), list_heads(), d_cutprev.p, pw.p, lp_lo.p, lp_hi.p, dr.p, tol_p, yth.p,
                          d_anynf.p + 1);
                 KTN_HIP(hipMemcpyAsync(xh.p, xth.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
                 KTN_HIP(hipMemcpyAsync(x0h.p, xth.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -1928,6 +1944,33 @@ int ktn_lp_truncate(ktn_handle h, int64_t nrows) {
         return KTN_OK;
     })
 }
+int ktn_lp_enable_global_lists(ktn_handle h, int64_t nl_total) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && nl_total >= 0, "enable_global_lists: no problem loaded");
+        KTN_REQUIRE(e->M == e->M_base, "enable_global_lists: call before the first cut");
+        e->d_glast.resize((size_t)std::max<int64_t>(nl_total, 1), e->stream);
+        KTN_HIP(hipMemsetAsync(e->d_glast.p, 0xFF, e->d_glast.n * sizeof(int64_t), e->stream));
+        e->nl_total = nl_total;
+        e->glists = true;
+        e->sync();
+        return KTN_OK;
+    })
+}
+int ktn_last_sweep_slots(ktn_handle h, int64_t* slots, int64_t cap, int64_t* count) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && count, "last_sweep_slots: bad arguments");
+        *count = e->last_sweep_cuts;
+        if (slots && e->last_sweep_cuts > 0) {
+            KTN_REQUIRE(cap >= e->last_sweep_cuts, "last_sweep_slots: buffer too small");
+            std::vector<int32_t> tmp((size_t)e->last_sweep_cuts);
+            e->d_violslots.download(tmp.data(), tmp.size(), e->stream);
+            for (size_t i = 0; i < tmp.size(); ++i) slots[i] = tmp[i];
+        }
+        return KTN_OK;
+    })
+}
 int ktn_lp_purge(ktn_handle h, int64_t* rows_removed) {
     KTN_TRY(h, {
         Engine* e = h->eng;
@@ -1940,6 +1983,10 @@ int ktn_lp_purge(ktn_handle h, int64_t* rows_removed) {
 }
 int ktn_lp_append_rows(ktn_handle h, int64_t nrows, const int64_t* rowptr, const int32_t* col, const double* val,
                        const double* lo, const double* hi) {
+    return ktn_lp_append_rows_nl(h, nrows, rowptr, col, val, lo, hi, nullptr);
+}
+int ktn_lp_append_rows_nl(ktn_handle h, int64_t nrows, const int64_t* rowptr, const int32_t* col, const double* val,
+                          const double* lo, const double* hi, const int64_t* nl_id) {
     KTN_TRY(h, {
         Engine* e = h->eng;
         KTN_REQUIRE(e->loaded && nrows >= 0, "append: bad arguments");
@@ -1963,6 +2010,7 @@ int ktn_lp_append_rows(ktn_handle h, int64_t nrows, const int64_t* rowptr, const
         e->d_age.resize((size_t)(e->M + nrows), s); e->d_cutprev.resize((size_t)(e->M + nrows), s);
         KTN_HIP(hipMemsetAsync(e->d_age.p + e->M, 0, (size_t)nrows * sizeof(int32_t), s));
         KTN_HIP(hipMemsetAsync(e->d_cutprev.p + e->M, 0xFF, (size_t)nrows * sizeof(int64_t), s));
+        if (nl_id && e->glists) e->append_link(nrows, nl_id);
         if (nz > 0) {
             KTN_HIP(hipMemcpyAsync(e->lp_col.p + e->NNZ, col + rowptr[0], (size_t)nz * 4, hipMemcpyHostToDevice, s));
             KTN_HIP(hipMemcpyAsync(e->lp_val.p + e->NNZ, val + rowptr[0], (size_t)nz * 8, hipMemcpyHostToDevice, s));

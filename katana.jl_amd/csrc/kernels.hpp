@@ -474,6 +474,25 @@ __global__ __launch_bounds__(kBlock) void k_compact(NlpDev P, const int32_t* __r
     last_cut[gid] = R;
 }
 
+// Rows appended from the host (multi-GPU exchange) join the per-NL-row cut lists through their GLOBAL NL-row id:
+// the same bookkeeping k_compact does for the rows of a local sweep (dual inheritance, list threading).
+__global__ __launch_bounds__(kBlock) void k_append_link(int64_t nrows, int64_t base_row, const int64_t* __restrict__ nl_id,
+                                                       int64_t nl_total, int64_t* __restrict__ glast,
+                                                       int64_t* __restrict__ cut_prev, double* __restrict__ y, int inherit) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nrows) return;
+    const int64_t R = base_row + i, g = nl_id[i];
+    double y0 = 0.0;
+    int64_t prev = -1;
+    if (g >= 0 && g < nl_total) {
+        prev = glast[g];
+        if (inherit && prev >= 0) { y0 = y[prev]; y[prev] = 0.0; }
+        glast[g] = R;                      // one cut per NL row and append: no two threads share g
+    }
+    y[R] = y0;
+    cut_prev[R] = prev;
+}
+
 // Dual-mass consolidation among the cuts of ONE nonlinear row (stall handler of the GPU LP).
 // Near the optimum successive cuts of a row are nearly parallel; PDHG moves multiplier mass between
 // two of them only at a rate proportional to the (tiny) violation and idles with the iterate stuck

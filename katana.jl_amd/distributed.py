@@ -41,20 +41,24 @@ def shard_instance(inst, rank, world):
         meta=dict(inst.meta, shard=(rank, world)))
 
 
-def pack_block(rowptr, col, val, lo, hi):
-    """one f64 buffer: [rowptr[1:], col, val, lo, hi]  (integers are exact in f64)"""
-    return np.concatenate([np.asarray(rowptr[1:], dtype=np.float64), np.asarray(col, dtype=np.float64),
-                           np.asarray(val, dtype=np.float64), np.asarray(lo, dtype=np.float64),
-                           np.asarray(hi, dtype=np.float64)])
+def pack_block(rowptr, col, val, lo, hi, ids=None):
+    """one f64 buffer: [rowptr[1:], col, val, lo, hi(, global NL-row ids)]  (integers are exact in f64)"""
+    parts = [np.asarray(rowptr[1:], dtype=np.float64), np.asarray(col, dtype=np.float64),
+             np.asarray(val, dtype=np.float64), np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)]
+    if ids is not None:
+        parts.append(np.asarray(ids, dtype=np.float64))
+    return np.concatenate(parts)
 
 
-def unpack_block(buf, nrows, nnz):
+def unpack_block(buf, nrows, nnz, with_ids=False):
     o = 0
     rp = np.concatenate([[0], buf[o:o + nrows].astype(np.int64)]); o += nrows
     col = buf[o:o + nnz].astype(np.int32); o += nnz
     val = buf[o:o + nnz].copy(); o += nnz
     lo = buf[o:o + nrows].copy(); o += nrows
-    hi = buf[o:o + nrows].copy()
+    hi = buf[o:o + nrows].copy(); o += nrows
+    if with_ids:
+        return rp, col, val, lo, hi, buf[o:o + nrows].astype(np.int64)
     return rp, col, val, lo, hi
 
 
@@ -62,7 +66,9 @@ def exchange_cuts(dist, block, device="cpu"):
     """All-gather one cut block per rank.  `block` = (rowptr, col, val, lo, hi) of the local cuts.
     Returns the list of blocks in rank order.  With dist=None (single process) it is the identity."""
     import torch
-    rowptr, col, val, lo, hi = block
+    with_ids = len(block) == 6
+    rowptr, col, val, lo, hi = block[:5]
+    ids = block[5] if with_ids else None
     nrows, nnz = len(lo), len(col)
     import os
     if dist is None or (dist.get_world_size() == 1 and not os.environ.get("KTN_FORCE_COLLECTIVE")):
@@ -72,16 +78,16 @@ def exchange_cuts(dist, block, device="cpu"):
     all_counts = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(all_counts, counts)                       # collective 1: sizes
     all_counts = [tuple(int(v) for v in c.cpu()) for c in all_counts]
-    width = max(3 * r + 2 * z for r, z in all_counts)
+    width = max((4 if with_ids else 3) * r + 2 * z for r, z in all_counts)
     if width == 0:
-        return [(np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0), np.zeros(0))
-                for _ in range(world)]
+        empty = (np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0), np.zeros(0))
+        return [empty + ((np.zeros(0, dtype=np.int64),) if with_ids else ()) for _ in range(world)]
     send = torch.zeros(width, dtype=torch.float64, device=device)
-    payload = pack_block(rowptr, col, val, lo, hi)
+    payload = pack_block(rowptr, col, val, lo, hi, ids)
     send[:len(payload)] = torch.from_numpy(payload).to(device)
     recv = [torch.empty(width, dtype=torch.float64, device=device) for _ in range(world)]
     dist.all_gather(recv, send)                               # collective 2: padded cut blocks
-    return [unpack_block(recv[r].cpu().numpy(), *all_counts[r]) for r in range(world)]
+    return [unpack_block(recv[r].cpu().numpy(), *all_counts[r], with_ids=with_ids) for r in range(world)]
 
 
 class ShardedKatanaModel:
@@ -89,7 +95,7 @@ class ShardedKatanaModel:
 
     def __init__(self, solver, inst, rank, world, dist=None, exchange_device=None):
         self.rank, self.world, self.dist = rank, world, dist
-        solver.gpu_options = dict(solver.gpu_options, lp_dual_inherit=0)
+        solver.gpu_options = dict(solver.gpu_options)
         if world > 1 and "cut_cap_factor" not in solver.gpu_options:
             # deepest-cut selection works per shard: split the cap so that the gathered LP gets what one GPU would add
             import ctypes as C
@@ -104,6 +110,10 @@ class ShardedKatanaModel:
         self.m = NonlinearModel(solver)
         self.m.loadproblem(self.local.n, self.local.num_constr, self.local.l_var, self.local.u_var,
                            self.local.l_constr, self.local.u_constr, self.local.sense, SeparableNLP(self.local))
+        # cuts carry the global id of their NL row, so that every rank's engine threads them into the per-row cut lists
+        # (dual inheritance, stall consolidation, purging) exactly as the single-GPU sweep does for its own cuts
+        self.shard_lo = shard_bounds(inst.m_nl, rank, world)[0]
+        self.m.lp_enable_global_lists(inst.m_nl)
         prm = self.m.params
         self.tol = dict(scale=prm.lp_tol_scale, floor=prm.lp_tol_floor, cap=prm.lp_tol_cap, gfloor=prm.lp_gap_floor,
                         gcap=prm.lp_gap_cap)
@@ -142,12 +152,12 @@ class ShardedKatanaModel:
         m0 = self.m.lp_num_rows()
         nv_local, mv_local = self.m.sweep_lp_point(f_tol)
         err_local = self.m.status() == "Error"
-        block = self.m.lp_rows_from(m0)
+        block = tuple(self.m.lp_rows_from(m0)) + (self.shard_lo + self.m.last_sweep_slots(),)
         self.m.lp_truncate(m0)
         blocks = exchange_cuts(self.dist, block, self.exchange_device)
         nviol = 0
-        for rp, col, val, lo, hi in blocks:                      # rank order => identical LP everywhere
-            self.m.lp_append_rows(rp, col, val, lo, hi)
+        for rp, col, val, lo, hi, ids in blocks:                 # rank order => identical LP everywhere
+            self.m.lp_append_rows(rp, col, val, lo, hi, ids)
             nviol += len(lo)
         self.exchanged_rows += nviol
         maxviol, any_err = self._allreduce_max(mv_local, 1.0 if err_local else 0.0)

@@ -193,7 +193,8 @@ class KatanaNonlinearModel:
         L.check(self._h, self._lib.ktn_lp_purge(self._h, C.byref(n)))
         return int(n.value)
 
-    def lp_append_rows(self, rowptr, col, val, lo, hi):
+    def lp_append_rows(self, rowptr, col, val, lo, hi, nl_id=None):
+        """append rows; `nl_id` = global NL-row id of the row each cut belongs to (after lp_enable_global_lists)"""
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
         nr = len(rowptr) - 1
         if nr <= 0:
@@ -202,8 +203,26 @@ class KatanaNonlinearModel:
         val, lo, hi = _f64(val), _f64(lo), _f64(hi)
         colp = col if len(col) else np.zeros(1, dtype=np.int32)
         valp = val if len(val) else np.zeros(1)
-        L.check(self._h, self._lib.ktn_lp_append_rows(self._h, nr, _p(rowptr, C.c_int64), _p(colp, C.c_int32), _p(valp),
-                                                      _p(lo), _p(hi)))
+        if nl_id is None:
+            idp = C.POINTER(C.c_int64)()
+        else:
+            nl_id = np.ascontiguousarray(nl_id, dtype=np.int64)
+            assert len(nl_id) == nr
+            idp = _p(nl_id, C.c_int64)
+        L.check(self._h, self._lib.ktn_lp_append_rows_nl(self._h, nr, _p(rowptr, C.c_int64), _p(colp, C.c_int32), _p(valp),
+                                                         _p(lo), _p(hi), idp))
+
+    def lp_enable_global_lists(self, nl_total):
+        L.check(self._h, self._lib.ktn_lp_enable_global_lists(self._h, int(nl_total)))
+
+    def last_sweep_slots(self):
+        """local NL slots of the cuts the last sweep appended, in row order"""
+        n = C.c_int64(0)
+        L.check(self._h, self._lib.ktn_last_sweep_slots(self._h, C.POINTER(C.c_int64)(), 0, C.byref(n)))
+        out = np.zeros(max(int(n.value), 1), dtype=np.int64)
+        if n.value:
+            L.check(self._h, self._lib.ktn_last_sweep_slots(self._h, _p(out, C.c_int64), len(out), C.byref(n)))
+        return out[:int(n.value)]
 
     def lp_pdhg_raw(self, x0, y0, eta, omega, iters):
         x0, y0 = _f64(x0), _f64(y0)

@@ -111,6 +111,9 @@ def test_pack_unpack_roundtrip_with_empty_and_ragged_blocks():
         got = unpack_block(pack_block(rp, col, val, lo, hi), len(lens), nnz)
         assert np.array_equal(got[0], rp) and np.array_equal(got[1], col) and np.array_equal(got[2], val)
         assert np.array_equal(got[3], lo) and np.array_equal(got[4], hi, equal_nan=True)
+        ids = rng.integers(0, 2 ** 40, len(lens))                   # global NL-row ids ride along as a sixth array
+        got = unpack_block(pack_block(rp, col, val, lo, hi, ids), len(lens), nnz, with_ids=True)
+        assert len(got) == 6 and np.array_equal(got[5], ids) and np.array_equal(got[1], col)
 
 
 def _worker_gpu(rank, world, port, out, inst_kw=None, solver_kw=None):
@@ -134,7 +137,7 @@ def test_two_rank_sharded_solve_matches_single_gpu():
     out = mp.Manager().dict()
     mp.spawn(_worker_gpu, args=(world, _free_port(), out), nprocs=world, join=True)
     inst = ktn.instances.make_instance(n=4000, m_nl=400, k=16, family="explog", seed=21)
-    single = hip_load_instance(ktn, inst, lp_dual_inherit=0, purge_age=0)
+    single = hip_load_instance(ktn, inst, purge_age=0)
     assert single.optimize() == "Optimal"
     (s0, o0, it0, c0, x0, *_), (s1, o1, it1, c1, x1, *_) = out[0], out[1]
     assert s0 == s1 == "Optimal"
@@ -153,7 +156,7 @@ def test_sharded_model_world1_equals_engine_loop():
     inst = ktn.instances.make_instance(n=2000, m_nl=200, k=16, family="quad", seed=5)
     a = ShardedKatanaModel(ktn.KatanaSolver(log_level=0), inst, 0, 1, None)
     assert a.optimize() == "Optimal"
-    b = hip_load_instance(ktn, inst, lp_dual_inherit=0, purge_age=0)
+    b = hip_load_instance(ktn, inst, purge_age=0)
     assert b.optimize() == "Optimal"
     assert a.getobjval() == b.getobjval() and a.numiters() == b.numiters() and a.numcuts() == b.numcuts()
 
@@ -187,6 +190,6 @@ def test_sharded_world1_with_purging_equals_engine_loop():
     kw = dict(purge_age=2, purge_min_rows=300, cut_cap_factor=1.0, cut_cap_min=200)
     a = ShardedKatanaModel(ktn.KatanaSolver(log_level=0, **kw), inst, 0, 1, None)
     assert a.optimize() == "Optimal" and a.purged_rows > 0
-    b = hip_load_instance(ktn, inst, lp_dual_inherit=0, **kw)
+    b = hip_load_instance(ktn, inst, **kw)
     assert b.optimize() == "Optimal"
     assert a.getobjval() == b.getobjval() and a.numiters() == b.numiters() and a.numcuts() == b.numcuts()
