@@ -30,6 +30,8 @@ def oracle_solve_kat(m, **kw):
 
 
 def hip_model_from_kat(ktn, m, **solver_kw):
+    import json, os
+    solver_kw = dict(json.loads(os.environ.get("KTN_TEST_OPTS", "{}")), **solver_kw)      # experiments: override solver defaults
     M = ktn.Model(solver=ktn.KatanaSolver(log_level=0, **solver_kw))
     for v in m["vars"]:
         M.variable(v["lb"], v["ub"])
