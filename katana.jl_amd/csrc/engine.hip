@@ -1089,6 +1089,17 @@ void Engine::find_long_rows() {
     KTN_HIP(hipMemcpyAsync(&cnt, d_anynf.p + 1, 4, hipMemcpyDeviceToHost, stream));
     sync();
     n_long = cnt;
+    if (n_long > 1) {
+        // k_find_long appends with an atomic counter: the ORDER of the list depends on scheduling, and the check kernels
+        // accumulate the long rows in list order.  Sort it (a handful of entries) so that every sum -- and with it every
+        // restart decision, on every rank of a sharded run -- is reproducible.
+        std::vector<int32_t> tmp((size_t)n_long);
+        KTN_HIP(hipMemcpyAsync(tmp.data(), d_longrows.p, (size_t)n_long * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        sync();
+        std::sort(tmp.begin(), tmp.end());
+        KTN_HIP(hipMemcpyAsync(d_longrows.p, tmp.data(), (size_t)n_long * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        sync();
+    }
 }
 
 // y-step over all rows: G lanes per row for ordinary rows, a workgroup per row for the long ones
