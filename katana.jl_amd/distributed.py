@@ -145,8 +145,11 @@ class ShardedKatanaModel:
         tol_p = min(max(self.tol["scale"] * self.last_maxviol, floor_p), self.tol["cap"])
         tol_g = min(max(tol_p, self.tol["gfloor"]), self.tol["gcap"])
         lp_status, _ = self.m.lp_solve(tol_p, tol_g)
-        if lp_status != "Optimal":
-            self._status = lp_status
+        # every rank must leave the loop in the same iteration (a rank that returned early would leave the others
+        # waiting in the next collective): agree on "some LP did not end :Optimal"
+        bad, _ = self._allreduce_max(0.0 if lp_status == "Optimal" else 1.0, 0.0)
+        if bad > 0:
+            self._status = lp_status if lp_status != "Optimal" else "Error"
             return True
         self.purged_rows += self.m.lp_purge()                     # identical LPs => identical purge on every rank
         m0 = self.m.lp_num_rows()
