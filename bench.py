@@ -16,6 +16,8 @@ Prints ONE JSON line (rank 0).  `value` = ECP iterations / second, whole job.
                   bytes per launch / mean launch duration from the start/stop hipEvents of
                   hipExtLaunchKernelGGL on the engine's own stream, in a second, identical pass over the
                   same K steps (profile=1).
+  sweep_roofline -- the separator sweep (k_sep_eval_blk + k_sep_combine) on the HBM-resident variant of the workload
+                  (cfg3_hbm: 2048 instead of 32 entries per NL row, 411 MB per pass), same timing.
   cpu_baseline -- the CPU oracle (serial restatement of the reference + HiGHS dual simplex, 1 core)
                   on a bounded sample: the same family at half scale, full solve to f_tol.
 """
