@@ -129,6 +129,9 @@ typedef struct {
                                        many of the deepest (largest g - ub / lb - g) get a cut in this iteration; the stop
                                        rule still needs EVERY row within f_tol.  0 = cut every violated row            */
     int64_t cut_cap_min;    /* 10000                                                                                    */
+    double  lp_stag_factor; /* 100     primal-stagnation exit of the LP: rows feasible, primal objective flat over three checks,
+                                       gap within lp_stag_factor * tolerance (the dual of a degenerate LP crawls long after
+                                       the primal has converged); 0 = only the full gap criterion                        */
 } ktn_params;
 
 /* The device-evaluable statement of the NLP: replaces the

@@ -1294,6 +1294,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     const double eta_safe = 0.998 / std::max(identity_scaling ? fro : std::min(1.0, fro), 1e-12);
     double eta = std::max(0.998 / std::max(smax, 1e-12), eta_safe);
     int stall = 0, flat_rows = 0, consolidations = 0, infeas_hits = 0;
+    double pobj_h[3] = {1e300, -1e300, 1e300};
     double r_last_check = 0.0;
     sync();
     stats["lp_setup_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1389,7 +1390,24 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         if (dbg_lp) std::fprintf(stderr, "[lp mode %d] it %7lld k %6lld r %.3e pviol %.3e dres %.3e gap %.3e pobj %.10g dobj %.10g om %.3g eta %.3g\n",
                                  mode, (long long)it, (long long)k, r, pviol, dres, gap, pobj, dobj, om, eta);
         R.pobj = pobj; R.dobj = dobj; R.row_viol = pviol; R.gap = gap;
-        const bool done = (pviol <= tol_p) && (gap <= tol_g) && (dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2)));
+        bool done = (pviol <= tol_p) && (gap <= tol_g) && (dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2)));
+        // Primal-stagnation exit (lp_stag_factor).  On LPs with degenerate duals the primal part converges within a few
+        // hundred iterations while the duality gap crawls for 10 000 more: stop when the rows are
+        // feasible to tol_p, the dual residual is converged, the primal objective has not moved by more than 0.1 tol_g
+        // over the last three checks, and the gap is certified to lp_stag_factor * tol_g.
+        {
+            const double stag = prm.lp_stag_factor;
+            if (stag > 0.0 && mode == 0 && !done) {
+                const double scale = 1.0 + std::fabs(pobj);
+                const bool flat = std::fabs(pobj - pobj_h[0]) <= 0.1 * tol_g * scale && std::fabs(pobj - pobj_h[1]) <= 0.1 * tol_g * scale &&
+                                  std::fabs(pobj - pobj_h[2]) <= 0.1 * tol_g * scale;
+                if (flat && pviol <= tol_p && gap <= stag * tol_g && dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2))) {
+                    done = true;
+                    stats["lp_stagnation_exits"] += 1.0;
+                }
+            }
+            pobj_h[2] = pobj_h[1]; pobj_h[1] = pobj_h[0]; pobj_h[0] = pobj;
+        }
         if (done || !(r == r)) {
             R.status = done ? KTN_STATUS_OPTIMAL : KTN_STATUS_ERROR;
             ++it;
@@ -1671,6 +1689,7 @@ void ktn_default_params(ktn_params* p) {
     p->purge_age = 2; p->purge_margin = 1e-3; p->purge_min_frac = 0.05; p->purge_min_rows = 2000;
     p->lp_dense_after = 5000;
     p->cut_cap_factor = 2.0; p->cut_cap_min = 10000;
+    p->lp_stag_factor = 100.0;
 }
 
 int ktn_create(const ktn_params* p, ktn_handle* out) {

@@ -199,3 +199,21 @@ def test_full_size_cfg4_one_million_nonlinear_rows():
     assert np.max(np.abs(x - inst.xhat)) <= 1e-3
     assert m.stat("cut_selections") >= 1 and m.stat("purged_rows") > 0
     assert m.numcuts() < 3 * inst.m_nl and m.lp_num_rows() < inst.m_lin + inst.m_nl // 2
+
+
+def test_primal_stagnation_exit_of_the_lp_keeps_the_answer():
+    """lp_stag_factor: on a seed whose floor-tolerance LP has a crawling dual the LP stops on primal stagnation + a gap
+    certified to 100x the tolerance; answer and feasibility as with the full gap criterion, in fewer PDHG iterations"""
+    inst = ktn.instances.make_config("cfg3", seed=3)
+    res = {}
+    for f in (0.0, 100.0):
+        m = hip_load_instance(ktn, inst, lp_stag_factor=f)
+        assert m.optimize() == "Optimal"
+        x = m.getsolution()
+        assert abs(m.getobjval() - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+        assert max_nl_violation(inst, x) <= 1e-6 * (1 + 1e-6)
+        assert np.max(np.abs(x - inst.xhat)) <= 1e-3
+        res[f] = (m.stat("pdhg_iters"), m.stat("lp_stagnation_exits"), m.getobjval())
+    assert res[0.0][1] == 0 and res[100.0][1] >= 1
+    assert res[100.0][0] < 0.7 * res[0.0][0]
+    assert abs(res[0.0][2] - res[100.0][2]) <= 2e-6 * max(1.0, abs(res[0.0][2]))
