@@ -775,8 +775,11 @@ __device__ __forceinline__ void chk_row_accumulate(ChkAcc& a, int64_t i, double 
     const double ytv = yt[i], dy = ytv - y[i];
     a.s[0] += dy * (axt - axk);
     a.s[1] += dy * dy;
-    if (ytv > 0.0) { a.s[2] += lo[i] * ytv; a.s[10] += fabs(lo[i] * ytv); }   // lo finite whenever yt > 0
-    else if (ytv < 0.0) { a.s[2] += hi[i] * ytv; a.s[10] += fabs(hi[i] * ytv); }
+    // The projection makes yt sign-feasible (yt > 0 only where lo is finite) up to ROUNDING: v + sigma * (-v / sigma) can
+    // leave a residue of a few 1e-17 with the wrong sign, and -inf * 1e-17 = -inf would void the duality gap of this
+    // check (seen at every second check of a slowly converging solve).  Such residues carry no dual objective.
+    if (ytv > 0.0) { if (lo[i] > -__builtin_inf()) { a.s[2] += lo[i] * ytv; a.s[10] += fabs(lo[i] * ytv); } }
+    else if (ytv < 0.0) { if (hi[i] < __builtin_inf()) { a.s[2] += hi[i] * ytv; a.s[10] += fabs(hi[i] * ytv); } }
     const double d0 = ytv - y0[i];
     a.s[3] += d0 * d0;
     a.s[4] += ytv * ytv;
