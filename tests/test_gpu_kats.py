@@ -107,12 +107,11 @@ def test_max_sense_with_nonlinear_objective():
 
 # ---- host-evaluator fallback (KTN_ROW_HOST, SURVEY.md section 8b "Evaluator consumed") -------------------------------
 # A caller whose MathProgBase evaluator cannot hand over expressions passes callbacks instead; here the oracle's
-# evaluator plays that caller-side `d`.  Same expectations as the device-evaluated run above.
-HOST_IDS = ["basic_1", "basic_2", "001_01", "002_02", "101_01", "102_03", "103_04", "105_01", "105_04", "107_02", "108_01",
-            "110_02", "201_01", "202_03", "205_01", "210_02", "501_01_n1", "501_01_n7", "501_02_n12", "501_02_n20"]
+# evaluator plays that caller-side `d`.  All 82 models, same expectations as the device-evaluated run above.
 
 
-@pytest.mark.parametrize("m", [k for k in KATS if k["id"] in HOST_IDS], ids=lambda k: k["id"])
+
+@pytest.mark.parametrize("m", KATS, ids=lambda k: k["id"])
 def test_reference_kat_through_host_evaluator_callbacks(m):
     from oracle.evaluators import SexprNLPEvaluator
     n, mc = len(m["vars"]), len(m["constraints"])
