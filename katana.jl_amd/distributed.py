@@ -62,9 +62,11 @@ def unpack_block(buf, nrows, nnz, with_ids=False):
     return rp, col, val, lo, hi
 
 
-def exchange_cuts(dist, block, device="cpu"):
-    """All-gather one cut block per rank.  `block` = (rowptr, col, val, lo, hi) of the local cuts.
-    Returns the list of blocks in rank order.  With dist=None (single process) it is the identity."""
+def exchange_cuts(dist, block, device="cpu", scalars=None):
+    """All-gather one cut block per rank.  `block` = (rowptr, col, val, lo, hi[, ids]) of the local cuts.
+    Returns the list of blocks in rank order.  With dist=None (single process) it is the identity.
+    `scalars` = (a, b): two floats that ride along with the size exchange; the call then returns
+    (blocks, max over ranks of a, max over ranks of b) -- the loop's status flags need no collective of their own."""
     import torch
     with_ids = len(block) == 6
     rowptr, col, val, lo, hi = block[:5]
@@ -72,12 +74,21 @@ def exchange_cuts(dist, block, device="cpu"):
     nrows, nnz = len(lo), len(col)
     import os
     if dist is None or (dist.get_world_size() == 1 and not os.environ.get("KTN_FORCE_COLLECTIVE")):
-        return [block]
+        return [block] if scalars is None else ([block], float(scalars[0]), float(scalars[1]))
     world = dist.get_world_size()
-    counts = torch.tensor([nrows, nnz], dtype=torch.int64, device=device)
-    all_counts = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(all_counts, counts)                       # collective 1: sizes
-    all_counts = [tuple(int(v) for v in c.cpu()) for c in all_counts]
+    sa, sb = (0.0, 0.0) if scalars is None else scalars
+    counts = torch.tensor([float(nrows), float(nnz), float(sa), float(sb)], dtype=torch.float64, device=device)
+    all_counts = [torch.zeros(4, dtype=torch.float64, device=device) for _ in range(world)]
+    dist.all_gather(all_counts, counts)                       # collective 1: sizes (+ the two scalars)
+    all_counts = [c.cpu() for c in all_counts]
+    max_a, max_b = max(float(c[2]) for c in all_counts), max(float(c[3]) for c in all_counts)
+    all_counts = [(int(c[0]), int(c[1])) for c in all_counts]
+    blocks = _gather_blocks(dist, device, world, all_counts, with_ids, rowptr, col, val, lo, hi, ids)
+    return blocks if scalars is None else (blocks, max_a, max_b)
+
+
+def _gather_blocks(dist, device, world, all_counts, with_ids, rowptr, col, val, lo, hi, ids):
+    import torch
     width = max((4 if with_ids else 3) * r + 2 * z for r, z in all_counts)
     if width == 0:
         empty = (np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0), np.zeros(0))
@@ -145,26 +156,32 @@ class ShardedKatanaModel:
         tol_p = min(max(self.tol["scale"] * self.last_maxviol, floor_p), self.tol["cap"])
         tol_g = min(max(tol_p, self.tol["gfloor"]), self.tol["gcap"])
         lp_status, _ = self.m.lp_solve(tol_p, tol_g)
-        # every rank must leave the loop in the same iteration (a rank that returned early would leave the others
-        # waiting in the next collective): agree on "some LP did not end :Optimal"
-        bad, _ = self._allreduce_max(0.0 if lp_status == "Optimal" else 1.0, 0.0)
-        if bad > 0:
-            self._status = lp_status if lp_status != "Optimal" else "Error"
-            return True
-        self.purged_rows += self.m.lp_purge()                     # identical LPs => identical purge on every rank
+        lp_ok = lp_status == "Optimal"
         m0 = self.m.lp_num_rows()
-        nv_local, mv_local = self.m.sweep_lp_point(f_tol)
-        err_local = self.m.status() == "Error"
-        block = tuple(self.m.lp_rows_from(m0)) + (self.shard_lo + self.m.last_sweep_slots(),)
-        self.m.lp_truncate(m0)
-        blocks = exchange_cuts(self.dist, block, self.exchange_device)
+        if lp_ok:
+            self.purged_rows += self.m.lp_purge()                 # identical LPs => identical purge on every rank
+            m0 = self.m.lp_num_rows()
+            nv_local, mv_local = self.m.sweep_lp_point(f_tol)
+            err_local = self.m.status() == "Error"
+            block = tuple(self.m.lp_rows_from(m0)) + (self.shard_lo + self.m.last_sweep_slots(),)
+            self.m.lp_truncate(m0)
+        else:                                                     # still take part in this iteration's exchange
+            mv_local, err_local = 0.0, False
+            block = (np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0), np.zeros(0),
+                     np.zeros(0, dtype=np.int64))
+        # Two collectives per iteration.  The status flags ride with the size exchange: every rank must leave the loop in
+        # the same iteration (one that returned early would leave the others waiting in the next collective).
+        flag = (2.0 if not lp_ok else 0.0) + (1.0 if err_local else 0.0)
+        blocks, maxviol, flags = exchange_cuts(self.dist, block, self.exchange_device, scalars=(mv_local, flag))
+        if flags >= 2.0:
+            self._status = lp_status if not lp_ok else "Error"
+            return True
         nviol = 0
         for rp, col, val, lo, hi, ids in blocks:                 # rank order => identical LP everywhere
             self.m.lp_append_rows(rp, col, val, lo, hi, ids)
             nviol += len(lo)
         self.exchanged_rows += nviol
-        maxviol, any_err = self._allreduce_max(mv_local, 1.0 if err_local else 0.0)
-        if any_err > 0:
+        if flags >= 1.0:
             self._status = "Error"
             return True
         self.last_maxviol = maxviol
