@@ -4,8 +4,8 @@ generated cuts per ECP iteration (no counterpart in the se
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on
 CPU for the tests).  Given x*, every nonlinear row is evaluated and cut independently
 (`for i in m.nlconstr_ixs`, src/model.jl:272-283), so rank r sweeps only its block of rows.
-The cuts are then all-gathered -- two collectives per iteration: the (rows, nnz) counts, then
-the cut blocks padded to the largest -- and appended on every rank in RANK ORDER, so that all
+The cuts are then all-gathered -- two collectives per iteration: the (rows, nnz) counts together with the
+status flags and the largest violation, then the cut blocks padded to the largest -- and appended on every rank in RANK ORDER, so that all
 ranks hold the identical LP and the deterministic GPU LP gives them the identical x*.
 
 The loop below is the host-level statement of Engine::step (csrc/engine.hip) with the exchange
@@ -190,16 +190,6 @@ class ShardedKatanaModel:
         else:
             self.allsat = nviol == 0
         return self.allsat or self.iter >= self.p["iter_cap"]
-
-    def _allreduce_max(self, a, b):
-        import os
-        if self.dist is None or (self.world == 1 and not os.environ.get("KTN_FORCE_COLLECTIVE")):
-            return a, b
-        import torch
-        t = torch.tensor([a, b], dtype=torch.float64, device=self.exchange_device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        t = t.cpu()
-        return float(t[0]), float(t[1])
 
     def optimize_end(self):
         self.m.optimize_end()
