@@ -279,3 +279,26 @@ def test_replay_of_committed_oracle_traces(tr):
             assert np.allclose(dense, cut["coefs"], rtol=1e-12, atol=1e-12), (tr["id"], cut["row"], dense, cut["coefs"])
             for got, want in ((lo[r], cut["lo"]), (hi[r], cut["hi"])):
                 assert (got == want) if not np.isfinite(want) else abs(got - want) <= 1e-12 * max(1.0, abs(want))
+
+
+def test_full_size_hbm_resident_sweep_blocked_equals_row_kernel(monkeypatch):
+    """SURVEY.md section 8d's HBM-resident variant at FULL size (n = 1e5, 1e4 rows x 2048 entries = 2.05e7 Jacobian
+    entries): the column-blocked sweep and the row kernel flag the same rows and emit the same cuts"""
+    inst = ktn.instances.make_config("cfg3_hbm", seed=0, vertex=False)
+    x = np.random.default_rng(5).uniform(inst.l_var, inst.u_var)
+    out = []
+    for blocked in ("0", "1"):
+        monkeypatch.setenv("KTN_SWEEP_BLOCKED", blocked)
+        m = hip_load_instance(ktn, inst, cut_cap_factor=0.0)
+        sep = ktn.KatanaHipSeparator(m); sep.initialize()
+        m0 = m.lp_num_rows()
+        sep.precompute(x)
+        nv, mv = sep.sweep(1e-6)
+        rp, col, val, lo, hi = m.lp_rows_from(m0)
+        out.append((nv, mv, np.asarray(rp), np.asarray(col), np.asarray(val), np.asarray(hi)))
+        del m, sep
+    a, b = out
+    assert a[0] == b[0] and a[0] > 0
+    assert abs(a[1] - b[1]) <= 1e-11 * max(1.0, abs(a[1]))
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert np.allclose(a[5], b[5], rtol=1e-11, atol=1e-11)
