@@ -131,7 +131,8 @@ typedef struct {
     int64_t cut_cap_min;    /* 10000                                                                                    */
     double  lp_stag_factor; /* 100     primal-stagnation exit of the LP: rows feasible, primal objective flat over three checks,
                                        gap within lp_stag_factor * tolerance (the dual of a degenerate LP crawls long after
-                                       the primal has converged); 0 = only the full gap criterion                        */
+                                       the primal has converged), and a row violation that has stalled below 2x the row
+                                       tolerance with everything else converged is accepted; 0 = only the full criteria      */
 } ktn_params;
 
 /* The device-evaluable statement of the NLP: replaces the

@@ -217,3 +217,14 @@ def test_primal_stagnation_exit_of_the_lp_keeps_the_answer():
     assert res[0.0][1] == 0 and res[100.0][1] >= 1
     assert res[100.0][0] < 0.7 * res[0.0][0]
     assert abs(res[0.0][2] - res[100.0][2]) <= 2e-6 * max(1.0, abs(res[0.0][2]))
+
+
+def test_stalled_row_violation_is_accepted_below_twice_the_row_tolerance():
+    """dense epigraph cuts, final floor-tolerance LP: objective, gap and dual residual converged while one row idles 15 %
+    above tol_p = 0.3 f_tol (2.1e6 PDHG iterations without the acceptance rule); the answer is the planted optimum"""
+    inst = ktn.instances.make_instance(n=3000, m_nl=300, k=16, family="quad", seed=1, objective="quad")
+    m = hip_load_instance(ktn, inst)
+    assert m.optimize() == "Optimal"
+    assert m.stat("pdhg_iters") < 200000
+    assert abs(m.getobjval() - inst.opt_obj) <= 1e-7 * max(1.0, abs(inst.opt_obj))
+    assert max_nl_violation(inst, m.getsolution()[:inst.n]) <= 1e-6 * (1 + 1e-6)
