@@ -54,7 +54,10 @@ def _worker_exchange(rank, world, port, out):
     # a second, empty round (late ECP iterations exchange nothing)
     empty = (np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0), np.zeros(0))
     blocks2 = exchange_cuts(dist, empty, "cpu")
-    out[rank] = (blocks, [len(b[3]) for b in blocks2])
+    # with ids and the two piggybacked scalars (max violation, status flag): maxima over ranks come back with the blocks
+    ids = np.arange(len(_oracle_cut_block(local, x)[3]), dtype=np.int64) + 1000 * rank
+    blocks3, mx_a, mx_b = exchange_cuts(dist, tuple(_oracle_cut_block(local, x)) + (ids,), "cpu", scalars=(1.5 * (rank + 1), float(rank)))
+    out[rank] = (blocks, [len(b[3]) for b in blocks2], [b[5] for b in blocks3], mx_a, mx_b)
     dist.destroy_process_group()
 
 
@@ -70,8 +73,10 @@ def test_exchange_merges_shard_cuts_into_the_single_process_cut_set():
     full = _oracle_cut_block(inst, x)
     assert len(full[3]) > 2
     for rank in range(world):
-        blocks, empty_counts = out[rank]
+        blocks, empty_counts, ids3, mx_a, mx_b = out[rank]
         assert empty_counts == [0, 0]
+        assert mx_a == 1.5 * world and mx_b == float(world - 1)
+        assert all(np.array_equal(ids3[r], np.arange(len(ids3[r])) + 1000 * r) for r in range(world))
         rp = np.concatenate([[0]] + [b[0][1:] + off for b, off in
                                      zip(blocks, np.cumsum([0] + [len(b[1]) for b in blocks[:-1]]))])
         col = np.concatenate([b[1] for b in blocks]); val = np.concatenate([b[2] for b in blocks])
