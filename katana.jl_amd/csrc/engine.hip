@@ -1369,11 +1369,9 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         launch_y<false>(A, 0, rho, nullptr, nullptr);
         hipLaunchKernelGGL(k_chk_rows, dim3(kRedBlocks), dim3(kBlock), 0, stream, m, A, xh.p, xth.p, yh.p, yth.p, y0h.p,
                            loh.p, hih.p, dr.p, d_longrows.p, n_long, (n_long > 0 ? kLongRow : (int64_t)1 << 62), partials.p);
-        hipLaunchKernelGGL(k_chk_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, chkout.p);
         hipLaunchKernelGGL(k_chk_cols, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, AT, xh.p, xth.p, x0h.p, yth.p, ch.p,
                            lh.p, uh.p, dc.p, partials.p + (size_t)kRedBlocks * kChkQ);
-        hipLaunchKernelGGL(k_chk_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p + (size_t)kRedBlocks * kChkQ, kRedBlocks,
-                           chkout.p + kChkQ);
+        hipLaunchKernelGGL(k_chk_final, dim3(2), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, chkout.p);   // rows | columns
         check_launch();
         double q[2 * kChkQ];
         KTN_HIP(hipMemcpyAsync(q, chkout.p, sizeof(q), hipMemcpyDeviceToHost, stream));

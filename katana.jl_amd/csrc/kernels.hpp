@@ -749,6 +749,9 @@ __device__ __forceinline__ void chk_block_store(ChkAcc& a, double* partials) {
 __global__ __launch_bounds__(kRedBlocks) void k_chk_final(const double* __restrict__ partials, int nblocks,
                                                           double* __restrict__ out) {
     __shared__ double sh[kChkQ][kRedBlocks / 64];
+    // blockIdx.x selects the set of partials (0: row side, 1: column side): both reductions in ONE launch
+    partials += (int64_t)blockIdx.x * nblocks * kChkQ;
+    out += (int64_t)blockIdx.x * kChkQ;
     const int b = threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < kChkQ; ++q) {
