@@ -1467,10 +1467,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
                 KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
                 LAUNCH_1(k_consolidate, list_count(), stream, list_count(), list_heads(), d_cutprev.p, pw.p, lp_lo.p, lp_hi.p, dr.p, tol_p, yth.p,
                          d_anynf.p + 1);
-                KTN_HIP(hipMemcpyAsync(xh.p, xth.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
-                KTN_HIP(hipMemcpyAsync(x0h.p, xth.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
-                KTN_HIP(hipMemcpyAsync(yh.p, yth.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
-                KTN_HIP(hipMemcpyAsync(y0h.p, yth.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                LAUNCH_1(k_restart_set, std::max(n, m), stream, n, m, xth.p, xh.p, x0h.p, yth.p, yh.p, y0h.p);
                 k = 0;
                 r_last_check = 0.0;
                 ++it;
@@ -1488,20 +1485,14 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
                 om = std::exp(0.5 * std::log(dy / dx) + 0.5 * std::log(om));
                 om = std::min(std::max(om, omega_ref * 1e-3), omega_ref * 1e3);
             }
-            KTN_HIP(hipMemcpyAsync(xh.p, xth.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
-            KTN_HIP(hipMemcpyAsync(x0h.p, xth.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
-            if (m > 0) {
-                KTN_HIP(hipMemcpyAsync(yh.p, yth.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
-                KTN_HIP(hipMemcpyAsync(y0h.p, yth.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
-            }
+            LAUNCH_1(k_restart_set, std::max(n, m), stream, n, m, xth.p, xh.p, x0h.p, yth.p, yh.p, y0h.p);
             stats["lp_restarts"] += 1.0;
             k = 0;
             ++it;
             continue;
         }
         const double w = (double)(k + 1) / (double)(k + 2);
-        LAUNCH_1(k_halpern, n, stream, n, xh.p, xth.p, x0h.p, w, rho);
-        LAUNCH_1(k_halpern, m, stream, m, yh.p, yth.p, y0h.p, w, rho);
+        LAUNCH_1(k_halpern2, std::max(n, m), stream, n, m, xh.p, xth.p, x0h.p, yh.p, yth.p, y0h.p, w, rho);
         ++k; ++it;
         plain_next = true;       // (after a restart k == 0 and the next pass is a check again: it needs r0)
     }

@@ -712,6 +712,23 @@ __global__ __launch_bounds__(kBlock) void k_find_long(int64_t m, const int64_t* 
     if (rowptr[i + 1] - rowptr[i] > thresh) list[atomicAdd(count, 1)] = (int32_t)i;
 }
 
+// Restart: z <- T(z), anchor z0 <- T(z), primal and dual part in one launch (instead of four device-to-device copies).
+__global__ __launch_bounds__(kBlock) void k_restart_set(int64_t n, int64_t m, const double* __restrict__ xt, double* __restrict__ x,
+                                                       double* __restrict__ x0, const double* __restrict__ yt,
+                                                       double* __restrict__ y, double* __restrict__ y0) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) { const double v = xt[i]; x[i] = v; x0[i] = v; }
+    if (i < m) { const double v = yt[i]; y[i] = v; y0[i] = v; }
+}
+// Halpern update of the primal and the dual part in one launch
+__global__ __launch_bounds__(kBlock) void k_halpern2(int64_t n, int64_t m, double* __restrict__ x, const double* __restrict__ xt,
+                                                    const double* __restrict__ x0, double* __restrict__ y,
+                                                    const double* __restrict__ yt, const double* __restrict__ y0, double w, double rho) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) x[i] = w * ((1.0 + rho) * xt[i] - rho * x[i]) + (1.0 - w) * x0[i];
+    if (i < m) y[i] = w * ((1.0 + rho) * yt[i] - rho * y[i]) + (1.0 - w) * y0[i];
+}
+
 // Halpern update after a check iteration that neither terminated nor restarted.
 __global__ __launch_bounds__(kBlock) void k_halpern(int64_t n, double* __restrict__ z, const double* __restrict__ zt,
                                                     const double* __restrict__ z0, double w, double rho) {
