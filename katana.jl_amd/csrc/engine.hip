@@ -512,6 +512,18 @@ struct Engine {
     // ================================================================ LP ============
     void rebuild_csc();
     void purge_cuts();
+    // Capacity for the cut pool up front: growing a buffer is hipMalloc + copy + hipFree (which synchronises the device),
+    // and on a large instance the pool passes through a dozen sizes in the first iterations (cfg4: 2.5 of the 4.9 s of a
+    // cold solve).  HBM is plentiful (288 GB): reserve for three sweeps' worth of cuts.
+    void reserve_lp(int64_t rows, int64_t nnz) {
+        const size_t r = (size_t)rows + 1, z = (size_t)nnz + 1;
+        for (DBuf<double>* b : {&lp_lo, &lp_hi, &lp_y, &lp_lo2, &lp_hi2, &lp_y2, &dr, &statr, &loh, &hih, &yh, &y0h, &yth, &pw}) b->reserve(r, stream);
+        for (DBuf<int64_t>* b : {&lp_rowptr, &lp_rowptr2, &d_cutprev, &d_cutprev2, &d_keep, &d_keepnnz, &d_newidx, &d_newptr}) b->reserve(r, stream);
+        for (DBuf<int32_t>* b : {&d_age, &d_age2, &d_longrows}) b->reserve(r, stream);
+        for (DBuf<double>* b : {&lp_val, &lp_val2, &c_val, &c_sval, &r_sval}) b->reserve(z, stream);
+        for (DBuf<int32_t>* b : {&lp_col, &lp_col2, &c_row}) b->reserve(z, stream);
+        k_in.reserve(z, stream); k_out.reserve(z, stream); p_in.reserve(z, stream); p_out.reserve(z, stream);
+    }
     void find_long_rows();
     template <bool UPDATE>
     void launch_y(const SpMat& A, int step, double rho, hipEvent_t e0, hipEvent_t e1);
@@ -947,6 +959,16 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     lp_c.upload(cvec, stream); lp_l.upload(lv, stream); lp_u.upload(uv, stream);
     lp_x.resize((size_t)n_lp, stream); lp_x.zero(stream);
     M_base = M; NNZ_base = NNZ; numcuts_base = numcuts;
+    {
+        // room for three sweeps' worth of cuts (each sweep adds at most min(m_nl, cut cap) rows)
+        int64_t per_sweep = m_nl;
+        if (prm.cut_cap_factor > 0.0)
+            per_sweep = std::min<int64_t>(m_nl, std::max<int64_t>((int64_t)(prm.cut_cap_factor * (double)n_lp), prm.cut_cap_min));
+        const double avg_nl = m_nl ? (double)nnz_nl / (double)m_nl : 0.0;
+        const int64_t rows = M + 3 * per_sweep;
+        const int64_t nz = NNZ + (int64_t)(3.0 * (double)per_sweep * avg_nl);
+        if ((double)rows * 200.0 + (double)nz * 60.0 < 64e9) reserve_lp(rows, nz);     // stay far below the 288 GB
+    }
     sync();
     loaded = true;
     const int keep_status = status;
