@@ -2009,6 +2009,15 @@ int ktn_lp_enable_global_lists(ktn_handle h, int64_t nl_total) {
         KTN_HIP(hipMemsetAsync(e->d_glast.p, 0xFF, e->d_glast.n * sizeof(int64_t), e->stream));
         e->nl_total = nl_total;
         e->glists = true;
+        {   // the gathered cuts of ALL ranks land in this LP: reserve for them (the load-time reserve only knew the local shard)
+            const int64_t per_sweep = std::min<int64_t>(nl_total, std::max<int64_t>(2 * e->n_lp, 10000));
+            int64_t nnz_loc = 0;
+            for (auto r : e->h_nlrows) nnz_loc += e->h_rowptr[r + 1] - e->h_rowptr[r];
+            const double avg_nl = e->m_nl ? (double)nnz_loc / (double)e->m_nl : 0.0;
+            const int64_t rows = e->M + 3 * per_sweep;
+            const int64_t nz = e->NNZ + (int64_t)(3.0 * (double)per_sweep * avg_nl);
+            if ((double)rows * 200.0 + (double)nz * 60.0 < 64e9) e->reserve_lp(rows, nz);
+        }
         e->sync();
         return KTN_OK;
     })
