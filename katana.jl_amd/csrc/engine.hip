@@ -968,6 +968,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
         const int64_t rows = M + 3 * per_sweep;
         const int64_t nz = NNZ + (int64_t)(3.0 * (double)per_sweep * avg_nl);
         if ((double)rows * 200.0 + (double)nz * 60.0 < 64e9) reserve_lp(rows, nz);     // stay far below the 288 GB
+        d_violslots.reserve((size_t)std::max<int64_t>(m_nl, 1), stream);
     }
     sync();
     loaded = true;
