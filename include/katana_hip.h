@@ -133,6 +133,16 @@ typedef struct {
                                        gap within lp_stag_factor * tolerance (the dual of a degenerate LP crawls long after
                                        the primal has converged), and a row violation that has stalled below 2x the row
                                        tolerance with everything else converged is accepted; 0 = only the full criteria      */
+    int32_t lp_ruiz_warm;   /* 2       Ruiz passes when the scaling of the previous LP solve is reused for all but the appended rows
+                                       (0 = always lp_ruiz_iters passes from scratch)                                         */
+    /* terminal refinement of small problems: once every NL row is within f_tol (the reference's stop rule, src/model.jl:257,273)
+       the loop keeps cutting rows that are beyond polish_factor * f_tol, with the LP solved to the matching tolerance.  The
+       reference's exact simplex vertices end Kelley's method far below f_tol on its small test models (its suite asserts the
+       objective to 1e-6, test/3d.jl:124 to 1e-7); a first-order LP solution ends AT f_tol.  The point returned always
+       satisfies the reference's rule; these passes are not counted in numiters (stat "polish_iters").                       */
+    double  polish_factor;  /* 1e-3    0 or >= 1: off                                                                            */
+    int32_t polish_max_var; /* 32      only for problems with at most this many LP columns (where the exact LP kernel applies) */
+    int32_t polish_max_iter;/* 30      at most this many refinement passes                                                     */
 } ktn_params;
 
 /* The device-evaluable statement of the NLP: replaces the

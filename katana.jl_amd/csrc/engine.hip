@@ -227,24 +227,19 @@ struct Engine {
     DBuf<uint32_t> p_in, p_out;
     DBuf<char> d_sorttmp;
     DBuf<double> dr, dc, statr, statc, ch, lh, uh, loh, hih, xh, yh, x0h, y0h, xth, yth, xbar, pv, pw, box;
-    DBuf<double> partials, chkout, power_v;
+    DBuf<double> partials, chk_part, chkout, power_v;
     // exact small-LP path (dense_lp.hpp)
     int64_t lp_iter_budget = 0, dense_credit = 0, dense_run = 0;
     DBuf<int32_t> ds_W, ds_valid;
     DBuf<double> ds_dense, ds_out;
     DBuf<int32_t> d_longrows;
-    DBuf<double> d_sched;               // [0, kMaxChunk+2): plain chunks, [kMaxChunk+2, ...+4): check iterations
-    double* h_sched = nullptr;          // pinned, same two regions
     static constexpr int kMaxChunk = 512;
-    hipGraph_t lp_graph = nullptr;
-    hipGraphExec_t lp_graph_exec = nullptr;
-    int lp_graph_len = 0;
-    bool use_graph = true;
     int64_t n_long = 0;
     static constexpr int64_t kLongRow = 2048;
     double omega = 1.0;
     bool have_omega = false;
     int grp_rows = 8, grp_cols = 8;
+    int64_t scal_rows = 0, scal_cols = 0;   // dr[0, scal_rows) / dc[0, scal_cols) hold the scaling of the last solve
 
     // ---- run state ----
     int status = KTN_STATUS_NONE;
@@ -254,6 +249,26 @@ struct Engine {
     double last_maxviol = 1e300;
     double obj_prev = kInf;
     bool allsat = false, begun = false, tight_done = false;
+    // terminal refinement (DESIGN.md section 5 "Polish"): after the stop rule of model.jl:257,273 holds, small problems keep
+    // cutting at polish_factor * f_tol; the point returned is the best one that satisfies the reference's rule
+    bool polishing = false, polish_done = false;
+    int polish_count = 0;
+    double best_viol = kInf, best_obj = 0.0;
+    DBuf<double> d_xbest;
+    // print_header / print_stats bookkeeping  src/model.jl:209-217,252-254,284-303
+    int64_t log_cuts_lastprnt = 0, log_max_viol = 0, purged_total = 0;
+    void print_header() const {
+        std::printf("%-10s %-15s %-15s %-20s %-20s %-15s\n", "Iteration", "Total cuts", "Cuts added", "Max constr. viol.",
+                    "Avg constr. viol.", "Current cuts");
+    }
+    // model.jl:213-217.  "Current cuts" is numcuts in the reference (it never removes a cut, :215 TODO); here it is the
+    // number of cuts still in the LP after purging.
+    void print_stats(int64_t iter_lastprnt) const {
+        const double avg = (double)log_cuts_lastprnt / ((double)iter_lastprnt * (double)m_nl);
+        std::printf("%-10lld %-15lld %-15lld %-20lld %-20.2f %-15lld\n", (long long)iter, (long long)numcuts,
+                    (long long)log_cuts_lastprnt, (long long)log_max_viol, avg, (long long)(numcuts - purged_total));
+        std::fflush(stdout);
+    }
     std::chrono::steady_clock::time_point t_start;
     std::vector<std::vector<double>> lp_sols;
     std::map<std::string, double> stats;
@@ -282,18 +297,8 @@ struct Engine {
         chkout.resize(kChkQ * 2 + 8, stream);
         d_scal.resize(8, stream);
         d_anynf.resize(2, stream);
-        d_sched.resize(kMaxChunk + 8, stream);
-        KTN_HIP(hipHostMalloc((void**)&h_sched, (kMaxChunk + 8) * sizeof(double), hipHostMallocDefault));
-        use_graph = !prm.profile && std::getenv("KTN_NO_GRAPH") == nullptr;
-    }
-    void drop_graph() {
-        if (lp_graph_exec) { (void)hipGraphExecDestroy(lp_graph_exec); lp_graph_exec = nullptr; }
-        if (lp_graph) { (void)hipGraphDestroy(lp_graph); lp_graph = nullptr; }
-        lp_graph_len = 0;
     }
     ~Engine() {
-        drop_graph();
-        if (h_sched) (void)hipHostFree(h_sched);
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -478,6 +483,7 @@ struct Engine {
             stats["cuts_skipped"] += (double)(*nviol_out - V);
         }
         if (anynf) {   // model.jl:69-73: "Nonlinear constraint or objective likely undefined within domain"
+            std::fprintf(stderr, "WARNING: Nonlinear constraint or objective likely undefined within domain\n");
             *nonfinite_out = true;
             return;
         }
@@ -525,11 +531,10 @@ struct Engine {
         k_in.reserve(z, stream); k_out.reserve(z, stream); p_in.reserve(z, stream); p_out.reserve(z, stream);
     }
     void find_long_rows();
-    template <bool UPDATE>
-    void launch_y(const SpMat& A, int step, double rho, hipEvent_t e0, hipEvent_t e1);
-    void launch_x(const SpMat& AT, int step, double rho, bool update, hipEvent_t e0, hipEvent_t e1);
-    double* upload_sched(double tau, double sigma, int64_t k0, int nw, bool check_region);
-    const double* cur_sched = nullptr;
+    void launch_y(const SpMat& A, double sigma, double w, double rho, hipEvent_t e0, hipEvent_t e1);
+    void launch_x(const SpMat& AT, double tau, double w, double rho, bool update, hipEvent_t e0, hipEvent_t e1);
+    void launch_check(const SpMat& A, const SpMat& AT, double tau, double sigma);
+    int chk_nrow = 0, chk_ncol = 0;     // partial blocks of the last check (rows | columns)
     void compute_scaling(bool identity);
     LpResult lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling = false);
     LpResult lp_solve_core(double tol_p, double tol_g, int mode, bool identity_scaling);
@@ -542,6 +547,7 @@ struct Engine {
     void boundroutine();
     void begin();
     void step(int32_t* done);
+    void polish_step(int32_t* done);
     void end();
 };
 
@@ -896,6 +902,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     }
     std::vector<double> cvec(n_lp, 0.0);
     c0 = 0.0;
+    if (prm.log_level > 0) { std::printf(obj_linear ? "objective is linear\n" : "objective is nonlinear\n"); std::fflush(stdout); }   // model.jl:127,135
     if (obj_linear) {
         // gencut(fsep, pt, (0,0), num_constr+1), drop the fictitious aux variable  model.jl:129-133
         for (int64_t e = h_rowptr[m0]; e < h_rowptr[m0 + 1]; ++e)
@@ -915,6 +922,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
             else if (uf) vtx[j] = hi;
             else vtx[j] = 0.0;
         }
+        if (!ok) std::fprintf(stderr, "WARNING: Problem variables insufficiently bounded!\n");      // model.jl:156-157
         if (ok) {
             KTN_HIP(hipMemcpyAsync(d_xs.p, vtx.data(), (n0 + 1) * sizeof(double), hipMemcpyHostToDevice, stream));
             precompute_all(d_xs.p);
@@ -937,6 +945,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
             if (padzero[m0] && !(mx != mx)) mx = std::max(mx, 0.0);
             for (auto& cf : coef) if (cf + prm.cut_coef_rng < mx) cf = 0.0;   // round_coefs
             if (!finite) {
+                std::fprintf(stderr, "WARNING: Nonlinear constraint or objective likely undefined within domain\n");   // model.jl:70
                 status = KTN_STATUS_ERROR;              // _addcut: warn + :Error, no row added
             } else {
                 for (int64_t e = h_rowptr[m0]; e < h_rowptr[m0 + 1]; ++e) {
@@ -986,7 +995,7 @@ void Engine::reset() {
     d_lastcut.upload(neg1, stream);
     d_age.resize((size_t)std::max<int64_t>(M, 1), stream);
     d_age.zero(stream);
-    lp_dirty = true; have_omega = false; have_precompute = false; sharded_rows = false;
+    lp_dirty = true; have_omega = false; have_precompute = false; sharded_rows = false; scal_rows = 0;
     if (ds_valid.n) ds_valid.zero(stream);
     dense_credit = dense_run = 0;
     if (glists) KTN_HIP(hipMemsetAsync(d_glast.p, 0xFF, d_glast.n * sizeof(int64_t), stream));
@@ -995,6 +1004,8 @@ void Engine::reset() {
     status = KTN_STATUS_NONE; lp_status = KTN_STATUS_OPTIMAL;
     iter = 0; soltime = 0.0; objval = std::numeric_limits<double>::quiet_NaN();
     last_maxviol = 1e300; obj_prev = kInf; allsat = false; begun = false; tight_done = false;
+    log_cuts_lastprnt = 0; log_max_viol = 0; purged_total = 0;
+    polishing = false; polish_done = false; polish_count = 0; best_viol = kInf; best_obj = 0.0;
     lp_sols.clear();
     sync();
 }
@@ -1064,6 +1075,14 @@ void Engine::purge_cuts() {
         KTN_HIP(hipMemsetAsync(d_lastcut.p, 0xFF, d_lastcut.n * sizeof(int64_t), stream));
         KTN_HIP(hipMemsetAsync(d_cutprev2.p, 0xFF, (size_t)m_new * sizeof(int64_t), stream));
     }
+    if (scal_rows == m) {                         // keep the row scaling of the surviving rows (warm start of the next solve)
+        statr.resize((size_t)m, stream);
+        LAUNCH_1(k_compact_vec, m, stream, m, d_keep.p, d_newidx.p, dr.p, statr.p);
+        dr.swap(statr);
+        scal_rows = m_new;
+    } else {
+        scal_rows = 0;
+    }
     check_launch();
     sync();
     lp_rowptr.swap(lp_rowptr2); lp_col.swap(lp_col2); lp_val.swap(lp_val2); lp_lo.swap(lp_lo2); lp_hi.swap(lp_hi2);
@@ -1072,6 +1091,7 @@ void Engine::purge_cuts() {
     lp_lo.n = lp_hi.n = lp_y.n = d_age.n = d_cutprev.n = (size_t)m_new;
     if (ds_valid.n) ds_valid.zero(stream);          // row indices changed: the dense path's working set is void
     stats["purged_rows"] += (double)(m - m_new);
+    purged_total += m - m_new;
     stats["purges"] += 1.0;
     M = m_new; NNZ = nnz_new;
     lp_dirty = true;
@@ -1082,19 +1102,30 @@ void Engine::compute_scaling(bool identity) {
     dc.resize((size_t)n_lp, stream);
     statr.resize((size_t)std::max<int64_t>(M, 1), stream);
     statc.resize((size_t)n_lp, stream);
-    LAUNCH_1(k_fill, M, stream, M, dr.p, 1.0);
-    LAUNCH_1(k_fill, n_lp, stream, n_lp, dc.p, 1.0);
+    // Warm start (lp_ruiz_warm): rows are only ever appended, so dr / dc of the previous solve already equilibrate all but
+    // the new rows.  Those start at 1 and a few Ruiz passes + the final Pock-Chambolle pass (which alone carries the
+    // ||A^||_2 <= 1 guarantee, for any input scaling) replace the 10 passes from scratch.
+    const bool warm = !identity && prm.lp_ruiz_warm > 0 && scal_rows > 0 && scal_rows <= M && scal_cols == n_lp;
+    if (warm) {
+        LAUNCH_1(k_fill, M - scal_rows, stream, M - scal_rows, dr.p + scal_rows, 1.0);
+        stats["lp_scaling_warm"] += 1.0;
+    } else {
+        LAUNCH_1(k_fill, M, stream, M, dr.p, 1.0);
+        LAUNCH_1(k_fill, n_lp, stream, n_lp, dc.p, 1.0);
+    }
     const int gr = pick_group((double)NNZ / (double)std::max<int64_t>(M, 1));
     const int gc = pick_group((double)NNZ / (double)std::max<int64_t>(n_lp, 1));
     if (!identity && M > 0) {
-        for (int it = 0; it <= prm.lp_ruiz_iters; ++it) {
-            const int mode = (it == prm.lp_ruiz_iters) ? 1 : 0;   // last pass: Pock-Chambolle (alpha = 1)
+        const int passes = warm ? prm.lp_ruiz_warm : prm.lp_ruiz_iters;
+        for (int it = 0; it <= passes; ++it) {
+            const int mode = (it == passes) ? 1 : 0;   // last pass: Pock-Chambolle (alpha = 1)
             LAUNCH_G(gr, k_scale_stat, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, mode, statr.p);
             LAUNCH_G(gc, k_scale_stat, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, statc.p);
-            LAUNCH_1(k_scale_apply, M, stream, M, dr.p, statr.p);
-            LAUNCH_1(k_scale_apply, n_lp, stream, n_lp, dc.p, statc.p);
+            LAUNCH_1(k_scale_apply2, std::max(M, n_lp), stream, M, dr.p, statr.p, n_lp, dc.p, statc.p);
         }
     }
+    scal_rows = identity ? 0 : M;
+    scal_cols = n_lp;
     r_sval.resize((size_t)NNZ + 1, stream);
     c_sval.resize((size_t)NNZ + 1, stream);
     LAUNCH_G(gr, k_scale_vals, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, r_sval.p);
@@ -1125,38 +1156,47 @@ void Engine::find_long_rows() {
     }
 }
 
-// y-step over all rows: G lanes per row for ordinary rows, a workgroup per row for the long ones
-template <bool UPDATE>
-void Engine::launch_y(const SpMat& A, int step, double rho, hipEvent_t e0, hipEvent_t e1) {
+// y-step over all rows: G lanes per row for ordinary rows, a workgroup per row for the long ones.  Step sizes and the
+// Halpern weight travel as kernel arguments (eager launches: at ~6 us per kernel the host stays ahead of the GPU, and a
+// hipGraph of the chunk bought nothing measurable while its capture + instantiation cost every LP solve).
+void Engine::launch_y(const SpMat& A, double sigma, double w, double rho, hipEvent_t e0, hipEvent_t e1) {
     const int64_t m = M;
     const int64_t thr = n_long > 0 ? kLongRow : (int64_t)1 << 62;
-    if (e0) LAUNCH_GB_EV(grp_rows, k_pdhg_y, UPDATE, m, stream, e0, e1, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, cur_sched, step, rho, thr);
-    else LAUNCH_GB(grp_rows, k_pdhg_y, UPDATE, m, stream, m, A, xbar.p, yh.p, y0h.p, yth.p, loh.p, hih.p, cur_sched, step, rho, thr);
+    if (e0) LAUNCH_G_EV(grp_rows, k_pdhg_y, m, stream, e0, e1, m, A, xbar.p, yh.p, y0h.p, loh.p, hih.p, sigma, w, rho, thr);
+    else LAUNCH_G(grp_rows, k_pdhg_y, m, stream, m, A, xbar.p, yh.p, y0h.p, loh.p, hih.p, sigma, w, rho, thr);
     if (n_long > 0)
-        hipLaunchKernelGGL((k_pdhg_y_long<UPDATE>), dim3((unsigned)n_long), dim3(kLongBlock), 0, stream, d_longrows.p, A, xbar.p, yh.p,
-                           y0h.p, yth.p, loh.p, hih.p, cur_sched, step, rho);
+        hipLaunchKernelGGL((k_pdhg_y_long<false>), dim3((unsigned)n_long), dim3(kLongBlock), 0, stream, d_longrows.p, A, xbar.p,
+                           (const double*)nullptr, yh.p, y0h.p, yth.p, loh.p, hih.p, dr.p, sigma, w, rho, (double*)nullptr);
 }
-void Engine::launch_x(const SpMat& AT, int step, double rho, bool update, hipEvent_t e0, hipEvent_t e1) {
+void Engine::launch_x(const SpMat& AT, double tau, double w, double rho, bool update, hipEvent_t e0, hipEvent_t e1) {
     const int64_t n = n_lp;
     if (update) {
-        if (e0) LAUNCH_GB_EV(grp_cols, k_pdhg_x, true, n, stream, e0, e1, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, cur_sched, step, rho);
-        else LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, cur_sched, step, rho);
+        if (e0) LAUNCH_GB_EV(grp_cols, k_pdhg_x, true, n, stream, e0, e1, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        else LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
     } else {
-        LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, cur_sched, step, rho);
+        LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
     }
 }
-// sched = [tau, sigma, w_{k0}, w_{k0+1}, ...]: written to pinned memory and copied stream-ordered.
-// Plain chunks and check iterations use SEPARATE regions: a chunk is launched without a host
-// synchronisation, so the check that follows must not overwrite the pinned words its copy still reads
-// (between two uses of the same region there is always the check's synchronisation).
-double* Engine::upload_sched(double tau, double sigma, int64_t k0, int nw, bool check_region) {
-    const size_t off = check_region ? (size_t)kMaxChunk + 2 : 0;
-    double* h = h_sched + off;
-    h[0] = tau;
-    h[1] = sigma;
-    for (int j = 0; j < nw; ++j) h[2 + j] = (double)(k0 + j + 1) / (double)(k0 + j + 2);
-    KTN_HIP(hipMemcpyAsync(d_sched.p + off, h, (size_t)(2 + nw) * sizeof(double), hipMemcpyHostToDevice, stream));
-    return d_sched.p + off;
+// Check iteration: the PDHG step without update (xt, yt stored) and the KKT / fixed-point sums.  The row side rides on the
+// y-step (k_pdhg_y_chk gathers xt and x anyway); the column side needs A'yt and is one G-lanes-per-column pass.
+void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double sigma) {
+    const int64_t n = n_lp, m = M;
+    launch_x(AT, tau, 0.0, 1.0, false, nullptr, nullptr);
+    const int64_t thr = n_long > 0 ? kLongRow : (int64_t)1 << 62;
+    const int64_t brow = ceil_div(std::max<int64_t>(m, 1) * grp_rows, kBlock), bcol = ceil_div(n * grp_cols, kBlock);
+    chk_part.resize((size_t)(brow + n_long + bcol) * kChkQ, stream);
+    double* prow = chk_part.p;
+    double* pcol = chk_part.p + (size_t)(brow + n_long) * kChkQ;
+    if (m > 0) {
+        LAUNCH_G(grp_rows, k_pdhg_y_chk, m, stream, m, A, xth.p, xh.p, yh.p, y0h.p, yth.p, loh.p, hih.p, dr.p, sigma, thr, prow);
+        if (n_long > 0)
+            hipLaunchKernelGGL((k_pdhg_y_long<true>), dim3((unsigned)n_long), dim3(kLongBlock), 0, stream, d_longrows.p, A, xth.p, xh.p,
+                               yh.p, y0h.p, yth.p, loh.p, hih.p, dr.p, sigma, 0.0, 1.0, prow + (size_t)brow * kChkQ);
+    }
+    LAUNCH_G(grp_cols, k_chk_cols, n, stream, n, AT, xh.p, xth.p, x0h.p, yth.p, ch.p, lh.p, uh.p, dc.p, pcol);
+    chk_nrow = (m > 0) ? (int)(brow + n_long) : 0;
+    chk_ncol = (int)bcol;
+    hipLaunchKernelGGL(k_chk_final, dim3(2), dim3(kRedBlocks), 0, stream, prow, chk_nrow, pcol, chk_ncol, chkout.p);   // rows | columns
 }
 
 // LP dispatch.  The first-order method is the default: on the large sparse LPs of the hot path it is the only
@@ -1300,11 +1340,19 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         dot_dev(power_v.p, nrm);
         LAUNCH_1(k_normalize, n, stream, n, power_v.p, nrm, pv.p);
         const int iters = warm ? 8 : 20;
+        // The iterate is re-normalised only every fourth pass (and before the last, whose ||A'A v|| with ||v|| = 1 is the
+        // estimate): with ||A^||_2 <= 1 after the Pock-Chambolle pass the un-normalised vector only shrinks slowly, and the
+        // Rayleigh quotient does not depend on the scale -- 6 instead of 20 (dot, final sum, normalise) triples per LP solve.
         for (int it = 0; it < iters; ++it) {
             LAUNCH_G(grp_rows, k_spmv, m, stream, m, A, pv.p, pw.p);
-            LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, pw.p, xbar.p);
-            dot_dev(xbar.p, nrm);                           // ||A'A v||^2 with ||v|| = 1
-            LAUNCH_1(k_normalize, n, stream, n, xbar.p, nrm, pv.p);
+            const bool norm_now = (it % 4 == 3) || it >= iters - 2;
+            if (norm_now) {
+                LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, pw.p, xbar.p);
+                dot_dev(xbar.p, nrm);                       // on the last pass: ||A'A v||^2 with ||v|| = 1
+                LAUNCH_1(k_normalize, n, stream, n, xbar.p, nrm, pv.p);
+            } else {
+                LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, pw.p, pv.p);
+            }
         }
         double nv2 = 0.0;
         KTN_HIP(hipMemcpyAsync(&nv2, nrm, 8, hipMemcpyDeviceToHost, stream));
@@ -1339,7 +1387,6 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     R.status = KTN_STATUS_USERLIMIT;
     const int64_t max_it = lp_iter_budget > 0 ? std::min<int64_t>(lp_iter_budget, prm.lp_max_iter) : prm.lp_max_iter;
     const int chk = std::max(1, prm.lp_check_every);
-    drop_graph();      // pointers, sizes and group widths of this LP differ from the last one
     const int plain_len = std::min(chk - 1, (int)kMaxChunk);
     static const int first_chunk = std::getenv("KTN_FIRST_CHUNK") ? std::atoi(std::getenv("KTN_FIRST_CHUNK")) : 31;
     bool plain_next = false;
@@ -1353,48 +1400,24 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             const int want = (k <= 1 && first_chunk > 0) ? std::min(first_chunk, plain_len) : plain_len;
             const int np = (int)std::min<int64_t>(want, max_it - it);
             if (np <= 0) continue;
-            cur_sched = upload_sched(tau, sigma, k, np, false);
-            if (prm.profile) {
-                for (int j = 0; j < np; ++j) {
+            for (int j = 0; j < np; ++j) {
+                const double w = (double)(k + j + 1) / (double)(k + j + 2);
+                if (prm.profile) {
                     const size_t e0 = ev_get(), e1 = ev_get(), e2 = ev_get(), e3 = ev_get();
-                    launch_x(AT, j, rho, true, ev_pool[e0], ev_pool[e1]);
-                    launch_y<true>(A, j, rho, ev_pool[e2], ev_pool[e3]);
+                    launch_x(AT, tau, w, rho, true, ev_pool[e0], ev_pool[e1]);
+                    launch_y(A, sigma, w, rho, ev_pool[e2], ev_pool[e3]);
                     ev_recs.push_back({0, e0, e1, kx_bytes});
                     if (m > 0) ev_recs.push_back({1, e2, e3, ky_bytes});
-                }
-            } else if (use_graph && np == plain_len && np >= 8) {
-                if (!lp_graph_exec) {
-                    // capture the chunk once per LP solve; ThreadLocal so that other host threads (batch mode)
-                    // may keep calling hipMalloc / hipMemcpy on their own streams meanwhile
-                    KTN_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-                    for (int j = 0; j < np; ++j) {
-                        launch_x(AT, j, rho, true, nullptr, nullptr);
-                        launch_y<true>(A, j, rho, nullptr, nullptr);
-                    }
-                    KTN_HIP(hipStreamEndCapture(stream, &lp_graph));
-                    KTN_HIP(hipGraphInstantiate(&lp_graph_exec, lp_graph, nullptr, nullptr, 0));
-                    lp_graph_len = np;
-                    stats["lp_graph_captures"] += 1.0;
-                }
-                KTN_HIP(hipGraphLaunch(lp_graph_exec, stream));
-            } else {
-                for (int j = 0; j < np; ++j) {
-                    launch_x(AT, j, rho, true, nullptr, nullptr);
-                    launch_y<true>(A, j, rho, nullptr, nullptr);
+                } else {
+                    launch_x(AT, tau, w, rho, true, nullptr, nullptr);
+                    launch_y(A, sigma, w, rho, nullptr, nullptr);
                 }
             }
             k += np; it += np;
             continue;
         }
         // ---- check iteration: PDHG step without update, KKT + fixed-point residual
-        cur_sched = upload_sched(tau, sigma, k, 1, true);
-        launch_x(AT, 0, rho, false, nullptr, nullptr);
-        launch_y<false>(A, 0, rho, nullptr, nullptr);
-        hipLaunchKernelGGL(k_chk_rows, dim3(kRedBlocks), dim3(kBlock), 0, stream, m, A, xh.p, xth.p, yh.p, yth.p, y0h.p,
-                           loh.p, hih.p, dr.p, d_longrows.p, n_long, (n_long > 0 ? kLongRow : (int64_t)1 << 62), partials.p);
-        hipLaunchKernelGGL(k_chk_cols, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, AT, xh.p, xth.p, x0h.p, yth.p, ch.p,
-                           lh.p, uh.p, dc.p, partials.p + (size_t)kRedBlocks * kChkQ);
-        hipLaunchKernelGGL(k_chk_final, dim3(2), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, chkout.p);   // rows | columns
+        launch_check(A, AT, tau, sigma);
         check_launch();
         double q[2 * kChkQ];
         KTN_HIP(hipMemcpyAsync(q, chkout.p, sizeof(q), hipMemcpyDeviceToHost, stream));
@@ -1519,7 +1542,6 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         ++k; ++it;
         plain_next = true;       // (after a restart k == 0 and the next pass is a check again: it needs r0)
     }
-    drop_graph();
     R.iters = it;
     // un-scale the last PDHG point (xt, yt)
     if (mode == 0) {
@@ -1562,15 +1584,11 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
     if (m > 0) KTN_HIP(hipMemcpyAsync(y0h.p, yh.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
     find_long_rows();
     const double tau = eta / omega_, sigma = eta * omega_;
-    for (int64_t k = 0; k < iters;) {
-        const int np = (int)std::min<int64_t>(kMaxChunk, iters - k);
-        cur_sched = upload_sched(tau, sigma, k, np, false);
-        for (int j = 0; j < np; ++j) {
-            launch_x(AT, j, 1.0, true, nullptr, nullptr);
-            launch_y<true>(A, j, 1.0, nullptr, nullptr);
-        }
-        sync();
-        k += np;
+    for (int64_t k = 0; k < iters; ++k) {
+        const double w = (double)(k + 1) / (double)(k + 2);
+        launch_x(AT, tau, w, 1.0, true, nullptr, nullptr);
+        launch_y(A, sigma, w, 1.0, nullptr, nullptr);
+        if ((k & 255) == 255) sync();
     }
     check_launch();
     KTN_HIP(hipMemcpyAsync(x_out, xh.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1620,20 +1638,33 @@ void Engine::begin() {
     if (has_inf_bound) {       // presolve: resolve an initially-unbounded LP  model.jl:228-247
         int64_t i = 0;
         bool unb = recession_ray();
+        if (unb) std::fprintf(stderr, "WARNING: Automatically bounding unbounded LP\n");     // model.jl:229-231
         while (unb && i < n_lp) {
+            if (prm.log_level > 0) {                                                          // model.jl:237
+                std::vector<double> ray = d_ray.to_host(stream);
+                std::printf("Unbounded ray along: [");
+                for (int64_t j = 0; j < n_lp; ++j) std::printf(j ? ",%g" : "%g", ray[(size_t)j]);
+                std::printf("]\n");
+            }
             boundroutine();
             if (status == KTN_STATUS_ERROR) return;
             unb = recession_ray();
             ++i;
         }
-        if (unb) { lp_status = KTN_STATUS_UNBOUNDED; status = KTN_STATUS_UNBOUNDED; }
+        if (unb) {
+            std::fprintf(stderr, "WARNING: Katana could not resolve unbounded LP\n");         // model.jl:244-247
+            lp_status = KTN_STATUS_UNBOUNDED; status = KTN_STATUS_UNBOUNDED;
+            return;
+        }
     }
+    if (prm.log_level > 0) { print_header(); std::fflush(stdout); }                           // model.jl:249-251
 }
 
 void Engine::step(int32_t* done) {
     KTN_REQUIRE(begun, "ktn_ecp_step before ktn_optimize_begin");
     *done = 1;
     if (status == KTN_STATUS_ERROR || status == KTN_STATUS_UNBOUNDED) return;
+    if (polishing) { polish_step(done); return; }
     if (allsat || iter >= prm.iter_cap) return;          // while !allsat && m.iter < iter_cap  model.jl:257
     iter += 1;
     const double floor_p = prm.lp_tol_floor * prm.f_tol;
@@ -1659,11 +1690,84 @@ void Engine::step(int32_t* done) {
     const double obj = objval;                                           // model.jl:287-289
     const double obj_delta = std::fabs((obj_prev - obj) / obj);
     obj_prev = obj;
-    if (prm.log_level > 0 && (iter % prm.log_level == 0 || allsat))
-        std::printf("%-10lld %-15lld %-15lld %-20.3e %-15lld\n", (long long)iter, (long long)numcuts, (long long)nviol, mv,
-                    (long long)R.iters);
-    if (obj_delta <= prm.obj_eps) { allsat = true; }                     // model.jl:306-308 (break)
+    log_max_viol = std::max(log_max_viol, nviol);                        // model.jl:284-285
+    log_cuts_lastprnt += last_sweep_cuts;
+    if (prm.log_level > 0) {                                             // model.jl:291-303
+        const int64_t r = iter % prm.log_level;
+        if (r == 0) {
+            if (iter % ((int64_t)prm.log_level * 50) == 0) print_header();
+            print_stats(prm.log_level);
+            log_cuts_lastprnt = 0;
+            log_max_viol = 0;
+        } else if (allsat) {
+            print_stats(r);                                              // print on last iteration also
+        } else if (obj_delta <= prm.obj_eps) {
+            print_stats(iter);
+        }
+    }
+    const bool eps_stop = obj_delta <= prm.obj_eps;
+    if (eps_stop) { allsat = true; }                                     // model.jl:306-308 (break)
     *done = (allsat || iter >= prm.iter_cap) ? 1 : 0;
+    // Terminal refinement of small problems: the reference's simplex vertices end Kelley's method with the last
+    // violation far below f_tol (its tests ask the objective to 1e-6 / 1e-7); a first-order LP ends AT f_tol.
+    if (allsat && !eps_stop && !polish_done && !sharded_rows && prm.polish_factor > 0.0 && prm.polish_factor < 1.0 &&
+        prm.polish_max_iter > 0 && n_lp <= prm.polish_max_var && m_nl > 0) {
+        polishing = true;
+        polish_count = 0;
+        best_viol = kInf;
+        d_xbest.resize((size_t)n_lp, stream);
+        // The point that met the stop rule is a candidate for the answer; its largest violation among ALL rows (the
+        // sweep above only measured rows beyond f_tol, i.e. none) comes from a sweep at the polish tolerance below.
+        *done = 0;
+    }
+}
+
+// One pass of the terminal refinement: LP at the polish tolerance, cuts for every row beyond polish_factor * f_tol.
+// Ends when no such row is left, or after polish_max_iter passes; the answer is then the point with the smallest violation
+// among those that satisfy the reference's stop rule (every row within f_tol).
+void Engine::polish_step(int32_t* done) {
+    const double f_eff = prm.polish_factor * prm.f_tol;
+    int64_t nviol = 0;
+    double mv = 0.0;
+    bool nonfin = false;
+    auto consider = [&](double viol) {           // lp_x / objval hold a point whose largest violation is `viol` (<= f_tol)
+        if (viol <= prm.f_tol && viol < best_viol) {
+            best_viol = viol;
+            best_obj = objval;
+            KTN_HIP(hipMemcpyAsync(d_xbest.p, lp_x.p, (size_t)n_lp * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
+    };
+    auto finish = [&]() {
+        if (best_viol < kInf) {
+            KTN_HIP(hipMemcpyAsync(lp_x.p, d_xbest.p, (size_t)n_lp * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            objval = best_obj;
+            sync();
+        }
+        polishing = false;
+        polish_done = true;
+        *done = 1;
+    };
+    *done = 0;
+    if (polish_count == 0) {
+        // first pass: measure (and cut at) the point that met the stop rule
+        sweep(lp_x.p, f_eff, &nviol, &mv, &nonfin);
+        if (nonfin) { status = KTN_STATUS_ERROR; polishing = false; *done = 1; return; }
+        consider(mv);
+        polish_count = 1;
+        if (nviol == 0) finish();
+        return;
+    }
+    if (polish_count > prm.polish_max_iter) { finish(); return; }
+    ++polish_count;
+    stats["polish_iters"] += 1.0;
+    const double tol_p = prm.lp_tol_floor * f_eff;
+    const double tol_g = std::max(prm.lp_gap_floor * prm.polish_factor, 1e-12);
+    LpResult R = lp_solve(tol_p, tol_g, 0);
+    if (R.status != KTN_STATUS_OPTIMAL) { finish(); return; }            // keep the point that met the stop rule
+    sweep(lp_x.p, f_eff, &nviol, &mv, &nonfin);
+    if (nonfin) { finish(); return; }
+    consider(mv);
+    if (nviol == 0) finish();
 }
 
 void Engine::end() {
@@ -1717,6 +1821,8 @@ void ktn_default_params(ktn_params* p) {
     p->lp_dense_after = 5000;
     p->cut_cap_factor = 2.0; p->cut_cap_min = 10000;
     p->lp_stag_factor = 100.0;
+    p->lp_ruiz_warm = 2;
+    p->polish_factor = 1e-3; p->polish_max_var = 32; p->polish_max_iter = 30;
 }
 
 int ktn_create(const ktn_params* p, ktn_handle* out) {
@@ -1991,6 +2097,7 @@ int ktn_lp_truncate(ktn_handle h, int64_t nrows) {
         e->sync();
         e->numcuts -= (e->M - nrows);
         e->M = nrows; e->NNZ = base;
+        e->scal_rows = std::min(e->scal_rows, nrows);
         e->sharded_rows = true;
         if (e->ds_valid.n) e->ds_valid.zero(e->stream);
         e->lp_rowptr.n = (size_t)nrows + 1; e->lp_col.n = e->lp_val.n = (size_t)base;

@@ -620,19 +620,45 @@ struct SpMat {
     const double* val;   // scaled values
 };
 
+// Block-level accumulation of kChkQ quantities: [0..11] sums, [12..15] maxima.
+struct ChkAcc {
+    double s[kChkQ];
+    __device__ void init() {
+#pragma unroll
+        for (int q = 0; q < kChkQ; ++q) s[q] = 0.0;
+    }
+};
+// every thread of the block must call this (it holds a barrier); fixed-shape reduction: butterfly per wavefront,
+// then the block's wavefronts in order
+template <int BLOCK>
+__device__ __forceinline__ void chk_block_store(ChkAcc& a, double* partials) {
+    __shared__ double sh[kChkQ][BLOCK / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < kChkQ; ++q) {
+        double v = a.s[q];
+        if (q < 12) v = group_sum<64>(v); else v = group_max<64>(v);
+        if (lane == 0) sh[q][wv] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kChkQ) {
+        const int q = threadIdx.x;
+        double v = sh[q][0];
+        for (int k = 1; k < BLOCK / 64; ++k) v = (q < 12) ? v + sh[q][k] : fmax(v, sh[q][k]);
+        partials[(int64_t)blockIdx.x * kChkQ + q] = v;
+    }
+}
+
 // x-step + reflected Halpern update.  One group per column (CSC gather of y).
 //   xt = clip(x - tau (c - A'y), l, u);  xbar = 2 xt - x
-//   UPDATE: x <- w ((1+rho) xt - rho x) + (1-w) x0     else: store xt
+//   UPDATE: x <- w ((1+rho) xt - rho x) + (1-w) x0     else: store xt  (check iteration; xbar is not needed there,
+//   the check form of the y-step gathers xt and x itself)
 template <int G, bool UPDATE>
 __global__ __launch_bounds__(kBlock) void k_pdhg_x(int64_t n, SpMat AT, const double* __restrict__ y,
                                                    double* __restrict__ x, const double* __restrict__ x0,
                                                    double* __restrict__ xt, double* __restrict__ xbar,
                                                    const double* __restrict__ c, const double* __restrict__ l,
-                                                   const double* __restrict__ u, const double* __restrict__ sched,
-                                                   int step, double rho) {
-    // step sizes and Halpern weights live in device memory (sched = [tau, sigma, w_0, w_1, ...]) so that
-    // a captured hipGraph of a whole chunk of iterations can be replayed with new values
-    const double tau = sched[0], w = sched[2 + step];
+                                                   const double* __restrict__ u, double tau, double w, double rho) {
     const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     if (j >= n) return;
@@ -645,64 +671,133 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_x(int64_t n, SpMat AT, const do
     acc = group_sum<G>(acc);
     if (lane == 0) {
         const double xtv = clampd(xv - tau * (cj - acc), lj, uj);
-        xbar[j] = 2.0 * xtv - xv;
-        if (UPDATE) x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0j;
+        if (UPDATE) { xbar[j] = 2.0 * xtv - xv; x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0j; }
         else xt[j] = xtv;
     }
 }
 
+// KKT / fixed-point quantities, row side, accumulated by the check form of the y-step.
+//  s0 sum dy*(A dx)   s1 sum dy^2      s2 dual objective (rows)  s3 sum (yt-y0)^2  s4 sum yt^2
+//  s10 abs terms of the dual objective   m12 max unscaled row violation
+__device__ __forceinline__ void chk_row_accumulate(ChkAcc& a, double ytv, double yv, double y0v, double axt, double axk,
+                                                   double lo, double hi, double dri) {
+    const double dy = ytv - yv;
+    a.s[0] += dy * (axt - axk);
+    a.s[1] += dy * dy;
+    // The projection makes yt sign-feasible (yt > 0 only where lo is finite) up to ROUNDING: v + sigma * (-v / sigma) can
+    // leave a residue of a few 1e-17 with the wrong sign, and -inf * 1e-17 = -inf would void the duality gap of this
+    // check (seen at every second check of a slowly converging solve).  Such residues carry no dual objective.
+    if (ytv > 0.0) { if (lo > -__builtin_inf()) { a.s[2] += lo * ytv; a.s[10] += fabs(lo * ytv); } }
+    else if (ytv < 0.0) { if (hi < __builtin_inf()) { a.s[2] += hi * ytv; a.s[10] += fabs(hi * ytv); } }
+    const double d0 = ytv - y0v;
+    a.s[3] += d0 * d0;
+    a.s[4] += ytv * ytv;
+    const double viol = fmax(fmax(lo - axt, axt - hi), 0.0) / dri;
+    a.s[12] = fmax(a.s[12], viol);
+}
+
 // y-step + reflected Halpern update.  One group per row (CSR gather of xbar).
 //   v = y - sigma A xbar;  yt = v + sigma clip(-v/sigma, lo, hi)
-template <int G, bool UPDATE>
+template <int G>
 __global__ __launch_bounds__(kBlock) void k_pdhg_y(int64_t m, SpMat A, const double* __restrict__ xbar,
                                                    double* __restrict__ y, const double* __restrict__ y0,
-                                                   double* __restrict__ yt, const double* __restrict__ lo,
-                                                   const double* __restrict__ hi, const double* __restrict__ sched,
-                                                   int step, double rho, int64_t long_thresh) {
-    const double sigma = sched[1], w = sched[2 + step];
+                                                   const double* __restrict__ lo, const double* __restrict__ hi,
+                                                   double sigma, double w, double rho, int64_t long_thresh) {
     const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     if (i >= m) return;
     const int64_t beg = A.ptr[i], end = A.ptr[i + 1];
     if (end - beg > long_thresh) return;          // served by k_pdhg_y_long (a workgroup per row)
-    const double yv = y[i], loi = lo[i], hii = hi[i], y0i = UPDATE ? y0[i] : 0.0;
+    const double yv = y[i], loi = lo[i], hii = hi[i], y0i = y0[i];
     double acc = 0.0;
     for (int64_t e = beg + lane; e < end; e += G) acc += A.val[e] * xbar[A.idx[e]];
     acc = group_sum<G>(acc);
     if (lane == 0) {
         const double v = yv - sigma * acc;
         const double ytv = v + sigma * clampd(-v / sigma, loi, hii);
-        if (UPDATE) y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0i;
-        else yt[i] = ytv;
+        y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0i;
     }
 }
 
-// Long rows (dense epigraph cuts: n+1 entries): one 256-thread workgroup per row, fixed-shape
-// reduction (butterfly per wavefront, then 4 partials through LDS) => deterministic.
+// Check form of the y-step: no update; gathers xt and x (A xbar = 2 A xt - A x), stores yt and accumulates the row side of
+// the KKT / fixed-point sums -- the two extra SpMV passes a separate check kernel would need ride on the gathers the step
+// does anyway.  No early return: every thread reaches the block reduction.
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_pdhg_y_chk(int64_t m, SpMat A, const double* __restrict__ xt,
+                                                       const double* __restrict__ x, const double* __restrict__ y,
+                                                       const double* __restrict__ y0, double* __restrict__ yt,
+                                                       const double* __restrict__ lo, const double* __restrict__ hi,
+                                                       const double* __restrict__ dr, double sigma, int64_t long_thresh,
+                                                       double* __restrict__ partials) {
+    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    ChkAcc a; a.init();
+    const bool on = i < m;
+    const int64_t beg = on ? A.ptr[i] : 0, end = on ? A.ptr[i + 1] : 0;
+    const bool mine = on && (end - beg <= long_thresh);
+    double yv = 0.0, loi = 0.0, hii = 0.0, y0i = 0.0, dri = 1.0;
+    if (mine) { yv = y[i]; loi = lo[i]; hii = hi[i]; y0i = y0[i]; dri = dr[i]; }
+    double axt = 0.0, axk = 0.0;
+    if (mine)
+        for (int64_t e = beg + lane; e < end; e += G) {
+            const int c = A.idx[e];
+            const double v = A.val[e];
+            axt += v * xt[c];
+            axk += v * x[c];
+        }
+    axt = group_sum<G>(axt);
+    axk = group_sum<G>(axk);
+    if (mine && lane == 0) {
+        const double v = yv - sigma * (2.0 * axt - axk);
+        const double ytv = v + sigma * clampd(-v / sigma, loi, hii);
+        yt[i] = ytv;
+        chk_row_accumulate(a, ytv, yv, y0i, axt, axk, loi, hii, dri);
+    }
+    chk_block_store<kBlock>(a, partials);
+}
+
+// Long rows (dense epigraph cuts: n+1 entries): one 1024-thread workgroup per row, fixed-shape
+// reduction (butterfly per wavefront, then the partials through LDS) => deterministic.
 constexpr int kLongBlock = 1024;
-template <bool UPDATE>
+template <bool CHECK>
 __global__ __launch_bounds__(kLongBlock) void k_pdhg_y_long(const int32_t* __restrict__ rows, SpMat A,
-                                                        const double* __restrict__ xbar, double* __restrict__ y,
-                                                        const double* __restrict__ y0, double* __restrict__ yt,
-                                                        const double* __restrict__ lo, const double* __restrict__ hi,
-                                                        const double* __restrict__ sched, int step, double rho) {
-    const double sigma = sched[1], w = sched[2 + step];
+                                                        const double* __restrict__ xa, const double* __restrict__ xb,
+                                                        double* __restrict__ y, const double* __restrict__ y0,
+                                                        double* __restrict__ yt, const double* __restrict__ lo,
+                                                        const double* __restrict__ hi, const double* __restrict__ dr,
+                                                        double sigma, double w, double rho, double* __restrict__ partials) {
+    // plain: xa = xbar.  CHECK: xa = xt, xb = x; partials = this row's slot after the regular blocks' partials
     const int64_t i = rows[blockIdx.x];
     const int64_t beg = A.ptr[i], end = A.ptr[i + 1];
-    double acc = 0.0;
-    for (int64_t e = beg + threadIdx.x; e < end; e += kLongBlock) acc += A.val[e] * xbar[A.idx[e]];
-    __shared__ double sh[kLongBlock / 64];
+    double acc = 0.0, acc2 = 0.0;
+    for (int64_t e = beg + threadIdx.x; e < end; e += kLongBlock) {
+        const int c = A.idx[e];
+        const double v = A.val[e];
+        acc += v * xa[c];
+        if (CHECK) acc2 += v * xb[c];
+    }
+    __shared__ double sh[2][kLongBlock / 64];
     acc = group_sum<64>(acc);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    if (CHECK) acc2 = group_sum<64>(acc2);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = acc; sh[1][threadIdx.x >> 6] = acc2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double ax = 0.0;
-        for (int k = 0; k < kLongBlock / 64; ++k) ax += sh[k];
+        double ax = 0.0, ax2 = 0.0;
+        for (int k = 0; k < kLongBlock / 64; ++k) { ax += sh[0][k]; ax2 += sh[1][k]; }
         const double yv = y[i];
-        const double v = yv - sigma * ax;
-        const double ytv = v + sigma * clampd(-v / sigma, lo[i], hi[i]);
-        if (UPDATE) y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0[i];
-        else yt[i] = ytv;
+        if (CHECK) {
+            const double v = yv - sigma * (2.0 * ax - ax2);
+            const double ytv = v + sigma * clampd(-v / sigma, lo[i], hi[i]);
+            yt[i] = ytv;
+            ChkAcc a; a.init();
+            chk_row_accumulate(a, ytv, yv, y0[i], ax, ax2, lo[i], hi[i], dr[i]);
+#pragma unroll
+            for (int q = 0; q < kChkQ; ++q) partials[(int64_t)blockIdx.x * kChkQ + q] = a.s[q];
+        } else {
+            const double v = yv - sigma * ax;
+            const double ytv = v + sigma * clampd(-v / sigma, lo[i], hi[i]);
+            y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0[i];
+        }
     }
 }
 __global__ __launch_bounds__(kBlock) void k_find_long(int64_t m, const int64_t* __restrict__ rowptr, int64_t thresh,
@@ -720,7 +815,8 @@ __global__ __launch_bounds__(kBlock) void k_restart_set(int64_t n, int64_t m, co
     if (i < n) { const double v = xt[i]; x[i] = v; x0[i] = v; }
     if (i < m) { const double v = yt[i]; y[i] = v; y0[i] = v; }
 }
-// Halpern update of the primal and the dual part in one launch
+// Halpern update of the primal and the dual part in one launch (after a check iteration that neither terminated nor
+// restarted); also refreshes xbar = 2 xt - x_old for nobody: the next x-step recomputes it
 __global__ __launch_bounds__(kBlock) void k_halpern2(int64_t n, int64_t m, double* __restrict__ x, const double* __restrict__ xt,
                                                     const double* __restrict__ x0, double* __restrict__ y,
                                                     const double* __restrict__ yt, const double* __restrict__ y0, double w, double rho) {
@@ -729,50 +825,23 @@ __global__ __launch_bounds__(kBlock) void k_halpern2(int64_t n, int64_t m, doubl
     if (i < m) y[i] = w * ((1.0 + rho) * yt[i] - rho * y[i]) + (1.0 - w) * y0[i];
 }
 
-// Halpern update after a check iteration that neither terminated nor restarted.
-__global__ __launch_bounds__(kBlock) void k_halpern(int64_t n, double* __restrict__ z, const double* __restrict__ zt,
-                                                    const double* __restrict__ z0, double w, double rho) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) z[i] = w * ((1.0 + rho) * zt[i] - rho * z[i]) + (1.0 - w) * z0[i];
-}
-
-// Block-level accumulation of kChkQ quantities: [0..11] sums, [12..15] maxima.
-struct ChkAcc {
-    double s[kChkQ];
-    __device__ void init() {
-#pragma unroll
-        for (int q = 0; q < kChkQ; ++q) s[q] = 0.0;
-    }
-};
-__device__ __forceinline__ void chk_block_store(ChkAcc& a, double* partials) {
-    __shared__ double sh[kChkQ][kBlock / 64];
+// second stage of the deterministic reductions: ONE block of kRedBlocks threads per side; thread b owns the partial
+// blocks b, b + kRedBlocks, ... in that order (coalesced loads), then a fixed-shape butterfly + LDS tree -> run-to-run
+// identical sums.  blockIdx.x selects the side (0: rows, 1: columns): both reductions in ONE launch.
+__global__ __launch_bounds__(kRedBlocks) void k_chk_final(const double* __restrict__ prow, int nrow, const double* __restrict__ pcol,
+                                                          int ncol, double* __restrict__ out) {
+    __shared__ double sh[kChkQ][kRedBlocks / 64];
+    const double* partials = blockIdx.x ? pcol : prow;
+    const int nblocks = blockIdx.x ? ncol : nrow;
+    out += (int64_t)blockIdx.x * kChkQ;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < kChkQ; ++q) {
-        double v = a.s[q];
-        if (q < 12) v = group_sum<64>(v); else v = group_max<64>(v);
-        if (lane == 0) sh[q][wv] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kChkQ) {
-        const int q = threadIdx.x;
-        double v = sh[q][0];
-        for (int k = 1; k < kBlock / 64; ++k) v = (q < 12) ? v + sh[q][k] : fmax(v, sh[q][k]);
-        partials[(int64_t)blockIdx.x * kChkQ + q] = v;
-    }
-}
-// second stage of the deterministic reductions: ONE block of kRedBlocks threads, thread b owns
-// partial block b (coalesced loads), fixed-shape butterfly + LDS tree -> run-to-run identical sums
-__global__ __launch_bounds__(kRedBlocks) void k_chk_final(const double* __restrict__ partials, int nblocks,
-                                                          double* __restrict__ out) {
-    __shared__ double sh[kChkQ][kRedBlocks / 64];
-    // blockIdx.x selects the set of partials (0: row side, 1: column side): both reductions in ONE launch
-    partials += (int64_t)blockIdx.x * nblocks * kChkQ;
-    out += (int64_t)blockIdx.x * kChkQ;
-    const int b = threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int q = 0; q < kChkQ; ++q) {
-        double v = (b < nblocks) ? partials[(int64_t)b * kChkQ + q] : 0.0;
+        double v = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += kRedBlocks) {
+            const double p = partials[(int64_t)b * kChkQ + q];
+            v = (q < 12) ? v + p : fmax(v, p);
+        }
         v = (q < 12) ? group_sum<64>(v) : group_max<64>(v);
         if (lane == 0) sh[q][wv] = v;
     }
@@ -785,99 +854,45 @@ __global__ __launch_bounds__(kRedBlocks) void k_chk_final(const double* __restri
     }
 }
 
-// KKT / fixed-point quantities, row side (grid-stride, one thread per row: check
-// iterations run once per `lp_check_every` PDHG iterations and are not the hot kernel).
-//  s0 sum dy*(A dx)   s1 sum dy^2      s2 dual objective (rows)  s3 sum (yt-y0)^2  s4 sum yt^2
-//  m12 max unscaled row violation
-__device__ __forceinline__ void chk_row_accumulate(ChkAcc& a, int64_t i, double axt, double axk, const double* y,
-                                                   const double* yt, const double* y0, const double* lo, const double* hi,
-                                                   const double* dr) {
-    const double ytv = yt[i], dy = ytv - y[i];
-    a.s[0] += dy * (axt - axk);
-    a.s[1] += dy * dy;
-    // The projection makes yt sign-feasible (yt > 0 only where lo is finite) up to ROUNDING: v + sigma * (-v / sigma) can
-    // leave a residue of a few 1e-17 with the wrong sign, and -inf * 1e-17 = -inf would void the duality gap of this
-    // check (seen at every second check of a slowly converging solve).  Such residues carry no dual objective.
-    if (ytv > 0.0) { if (lo[i] > -__builtin_inf()) { a.s[2] += lo[i] * ytv; a.s[10] += fabs(lo[i] * ytv); } }
-    else if (ytv < 0.0) { if (hi[i] < __builtin_inf()) { a.s[2] += hi[i] * ytv; a.s[10] += fabs(hi[i] * ytv); } }
-    const double d0 = ytv - y0[i];
-    a.s[3] += d0 * d0;
-    a.s[4] += ytv * ytv;
-    const double viol = fmax(fmax(lo[i] - axt, axt - hi[i]), 0.0) / dr[i];
-    a.s[12] = fmax(a.s[12], viol);
-}
-__global__ __launch_bounds__(kBlock) void k_chk_rows(int64_t m, SpMat A, const double* __restrict__ x,
-                                                     const double* __restrict__ xt, const double* __restrict__ y,
-                                                     const double* __restrict__ yt, const double* __restrict__ y0,
-                                                     const double* __restrict__ lo, const double* __restrict__ hi,
-                                                     const double* __restrict__ dr, const int32_t* __restrict__ long_rows,
-                                                     int64_t n_long, int64_t long_thresh, double* __restrict__ partials) {
-    ChkAcc a; a.init();
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
-        if (A.ptr[i + 1] - A.ptr[i] > long_thresh) continue;
-        double axt = 0.0, axk = 0.0;
-        for (int64_t e = A.ptr[i]; e < A.ptr[i + 1]; ++e) {
-            const int c = A.idx[e];
-            const double v = A.val[e];
-            axt += v * xt[c];
-            axk += v * x[c];
-        }
-        chk_row_accumulate(a, i, axt, axk, y, yt, y0, lo, hi, dr);
-    }
-    // long rows: the whole workgroup reduces one row at a time
-    __shared__ double sh2[2][kBlock / 64];
-    for (int64_t li = blockIdx.x; li < n_long; li += gridDim.x) {
-        const int64_t i = long_rows[li];
-        double axt = 0.0, axk = 0.0;
-        for (int64_t e = A.ptr[i] + threadIdx.x; e < A.ptr[i + 1]; e += kBlock) {
-            const int c = A.idx[e];
-            const double v = A.val[e];
-            axt += v * xt[c];
-            axk += v * x[c];
-        }
-        axt = group_sum<64>(axt);
-        axk = group_sum<64>(axk);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) { sh2[0][threadIdx.x >> 6] = axt; sh2[1][threadIdx.x >> 6] = axk; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double st = 0.0, sk = 0.0;
-            for (int k = 0; k < kBlock / 64; ++k) { st += sh2[0][k]; sk += sh2[1][k]; }
-            chk_row_accumulate(a, i, st, sk, y, yt, y0, lo, hi, dr);
-        }
-    }
-    chk_block_store(a, partials);
-}
-
 //  s5 sum dx^2  s6 primal objective  s7 dual objective (bounds)  s8 sum (xt-x0)^2  s9 sum xt^2
 //  s10 Farkas value (bounds part)  s11 its absolute terms  m14 max reduced cost of the c=0 problem on an infinite bound
 //  m13 max unscaled dual residual (reduced cost not absorbable by a finite bound)
+// Column side of the check: A'yt needs yt, which only exists after the y-step, so this one SpMV pass stays a kernel of
+// its own -- G lanes per column over the whole chip, like the x-step.
+template <int G>
 __global__ __launch_bounds__(kBlock) void k_chk_cols(int64_t n, SpMat AT, const double* __restrict__ x,
                                                      const double* __restrict__ xt, const double* __restrict__ x0,
                                                      const double* __restrict__ yt, const double* __restrict__ c,
                                                      const double* __restrict__ l, const double* __restrict__ u,
                                                      const double* __restrict__ dc, double* __restrict__ partials) {
+    const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
     ChkAcc a; a.init();
-    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) {
-        double aty = 0.0;
-        for (int64_t e = AT.ptr[j]; e < AT.ptr[j + 1]; ++e) aty += AT.val[e] * yt[AT.idx[e]];
-        const double xtv = xt[j], dx = xtv - x[j];
+    const bool on = j < n;
+    const int64_t beg = on ? AT.ptr[j] : 0, end = on ? AT.ptr[j + 1] : 0;
+    double xtv = 0.0, xv = 0.0, x0v = 0.0, cj = 0.0, lj = 0.0, uj = 0.0, dcj = 1.0;
+    if (on) { xtv = xt[j]; xv = x[j]; x0v = x0[j]; cj = c[j]; lj = l[j]; uj = u[j]; dcj = dc[j]; }
+    double aty = 0.0;
+    for (int64_t e = beg + lane; e < end; e += G) aty += AT.val[e] * yt[AT.idx[e]];
+    aty = group_sum<G>(aty);
+    if (on && lane == 0) {
+        const double dx = xtv - xv;
         a.s[5] += dx * dx;
-        a.s[6] += c[j] * xtv;
-        const double r = c[j] - aty;
+        a.s[6] += cj * xtv;
+        const double r = cj - aty;
         double bad = 0.0;
-        if (r > 0.0) { if (isfinite(l[j])) a.s[7] += l[j] * r; else bad = r; }
-        else if (r < 0.0) { if (isfinite(u[j])) a.s[7] += u[j] * r; else bad = -r; }
-        const double d0 = xtv - x0[j];
+        if (r > 0.0) { if (isfinite(lj)) a.s[7] += lj * r; else bad = r; }
+        else if (r < 0.0) { if (isfinite(uj)) a.s[7] += uj * r; else bad = -r; }
+        const double d0 = xtv - x0v;
         a.s[8] += d0 * d0;
         a.s[9] += xtv * xtv;
-        a.s[13] = fmax(a.s[13], bad / dc[j]);
+        a.s[13] = fmax(a.s[13], bad / dcj);
         // Farkas value of yt: the dual objective with c = 0 (positive <=> the rows + bounds are infeasible)
         const double r0 = -aty;
-        if (r0 > 0.0) { if (isfinite(l[j])) { a.s[10] += l[j] * r0; a.s[11] += fabs(l[j] * r0); } else a.s[14] = fmax(a.s[14], r0); }
-        else if (r0 < 0.0) { if (isfinite(u[j])) { a.s[10] += u[j] * r0; a.s[11] += fabs(u[j] * r0); } else a.s[14] = fmax(a.s[14], -r0); }
+        if (r0 > 0.0) { if (isfinite(lj)) { a.s[10] += lj * r0; a.s[11] += fabs(lj * r0); } else a.s[14] = fmax(a.s[14], r0); }
+        else if (r0 < 0.0) { if (isfinite(uj)) { a.s[10] += uj * r0; a.s[11] += fabs(uj * r0); } else a.s[14] = fmax(a.s[14], -r0); }
     }
-    chk_block_store(a, partials);
+    chk_block_store<kBlock>(a, partials);
 }
 
 // ---------------------------------------------------------- diagonal scaling ------
@@ -905,6 +920,19 @@ __global__ __launch_bounds__(kBlock) void k_scale_apply(int64_t m, double* __res
     if (i >= m) return;
     const double s = stat[i];
     if (s > 0.0 && isfinite(s)) d[i] /= sqrt(s);
+}
+// rows and columns in one launch
+__global__ __launch_bounds__(kBlock) void k_scale_apply2(int64_t m, double* __restrict__ dr, const double* __restrict__ sr, int64_t n,
+                                                        double* __restrict__ dc, const double* __restrict__ sc) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < m) { const double s = sr[i]; if (s > 0.0 && isfinite(s)) dr[i] /= sqrt(s); }
+    if (i < n) { const double s = sc[i]; if (s > 0.0 && isfinite(s)) dc[i] /= sqrt(s); }
+}
+// out[newidx[r]] = in[r] for the kept rows (purge)
+__global__ __launch_bounds__(kBlock) void k_compact_vec(int64_t m, const int64_t* __restrict__ keep, const int64_t* __restrict__ newidx,
+                                                       const double* __restrict__ in, double* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r < m && keep[r]) out[newidx[r]] = in[r];
 }
 // sval_e = dself_i * a_e * dother_idx(e)
 template <int G>

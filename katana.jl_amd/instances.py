@@ -228,7 +228,10 @@ def make_instance(n, m_nl, k, family="explog", seed=0, m_lin=None, lin_nnz=8, B=
         xhat=xhat, opt_obj=opt, m_lin=m_lin, m_nl=m_nl,
         meta=dict(n=n, m_nl=m_nl, k=k, family=family, seed=seed, m_lin=m_lin, lin_nnz=lin_nnz, B=B,
                   active_frac=active_frac, objective=objective, n_active=int(active.sum()),
-                  vertex=bool(vertex), n_lin_active=int(lin_active.sum())))
+                  vertex=bool(vertex), n_lin_active=int(lin_active.sum()),
+                  # planted multipliers: an x with g_i(x) <= eps on the NL rows, a_r'x <= b_r + delta on the linear rows and the
+                  # bounds met exactly has  c'x >= c'xhat - eps * lam_sum - delta * mu_sum  (Lagrangian bound at xhat)
+                  lam_sum=float(lam.sum()), mu_sum=float(mu.sum())))
     return inst
 
 
@@ -266,6 +269,8 @@ def fuse_instances(insts):
         obj_p0=np.concatenate([i.obj_p0 for i in insts]), obj_p1=np.concatenate([i.obj_p1 for i in insts]),
         obj_const=float(sum(i.obj_const for i in insts)), xhat=np.concatenate([i.xhat for i in insts]),
         opt_obj=float(sum(i.opt_obj for i in insts)), m_lin=int(sum(i.m_lin for i in insts)),
-        m_nl=int(sum(i.m_nl for i in insts)), meta=dict(fused=len(insts)))
+        m_nl=int(sum(i.m_nl for i in insts)),
+        meta=dict(fused=len(insts), lam_sum=float(sum(i.meta.get("lam_sum", 0.0) for i in insts)),
+                  mu_sum=float(sum(i.meta.get("mu_sum", 0.0) for i in insts))))
     assert all(i.sense == fused.sense for i in insts)
     return fused, offs

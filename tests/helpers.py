@@ -32,7 +32,7 @@ def oracle_solve_kat(m, **kw):
 def hip_model_from_kat(ktn, m, **solver_kw):
     import json, os
     solver_kw = dict(json.loads(os.environ.get("KTN_TEST_OPTS", "{}")), **solver_kw)      # experiments: override solver defaults
-    M = ktn.Model(solver=ktn.KatanaSolver(log_level=0, **solver_kw))
+    M = ktn.Model(solver=ktn.KatanaSolver(**dict(dict(log_level=0), **solver_kw)))
     for v in m["vars"]:
         M.variable(v["lb"], v["ub"])
     M.objective(m["sense"], ktn.from_sexpr(m["objective"]), linear=m["objective_linear"])
@@ -42,10 +42,22 @@ def hip_model_from_kat(ktn, m, **solver_kw):
 
 
 def hip_load_instance(ktn, inst, **solver_kw):
-    m = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, **solver_kw))
+    m = ktn.NonlinearModel(ktn.KatanaSolver(**dict(dict(log_level=0), **solver_kw)))
     m.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense,
                   ktn.SeparableNLP(inst))
     return m
+
+
+def planted_obj_bound(inst, f_tol=1e-6, lp_gap=1e-7):
+    """Per-instance bound on |objective - planted optimum| at a point that meets the stop rule (src/model.jl:257,273).
+    xhat is a KKT point with multipliers lambda_i (NL rows), mu_r (linear rows) and bound multipliers, so for the convex
+    problem  f(x) >= f(xhat) - sum_i lambda_i max(g_i(x), 0) - sum_r mu_r max(a_r'x - b_r, 0)  for x inside the box.  The
+    loop stops with every g_i <= f_tol; the LP leaves the linear rows within its row tolerance (0.3 f_tol, accepted up to
+    twice that: DESIGN.md section 5), the box is met exactly (the prox clips), and the LP objective is certified to the
+    relative duality-gap floor lp_gap.  With a nonlinear objective the epigraph row f(x) - t <= 0 is one more NL row
+    with multiplier 1."""
+    lam = inst.meta["lam_sum"] + (1.0 if inst.meta.get("objective") == "quad" else 0.0)
+    return f_tol * (lam + 0.6 * inst.meta["mu_sum"]) + lp_gap * (1.0 + 2.0 * abs(inst.opt_obj))
 
 
 def max_nl_violation(inst, x):

@@ -2,16 +2,17 @@
 oracle finishes in seconds, and through size-independent properties at BASELINE.json's full size.
 
 Objective tolerance: both paths stop when every nonlinear row is within f_tol = 1e-6
-(src/model.jl:257,273); with multipliers O(1) on the active rows that leaves the LP objective
-within ~ f_tol * sum(lambda) of the optimum, so |obj_hip - obj_oracle| <= 1e-5 * max(1, |obj|)."""
+(src/model.jl:257,273).  The instances plant a KKT point with known multipliers, which gives a
+per-instance bound on the objective error at ANY point that meets the stop rule:
+f_tol * sum(lambda) + (LP row tolerance) * sum(mu) + LP gap (helpers.planted_obj_bound).  That bound --
+not a blanket relative tolerance -- is what is asserted, against the planted optimum and against the oracle."""
 import numpy as np
 import pytest
 
 import katana_jl_amd as ktn
-from helpers import hip_load_instance, max_nl_violation, oracle_solve_instance
+from helpers import hip_load_instance, max_nl_violation, oracle_solve_instance, planted_obj_bound
 
 pytestmark = pytest.mark.gpu
-OBJ_RTOL = 1e-5
 
 
 @pytest.mark.parametrize("n,m_nl,k,family", [(400, 40, 16, "explog"), (1000, 100, 16, "quad"),
@@ -22,8 +23,8 @@ def test_hip_matches_oracle(n, m_nl, k, family):
     assert m.optimize() == "Optimal"
     om = oracle_solve_instance(inst)
     assert om.getstatus() == "Optimal"
-    assert abs(m.getobjval() - om.getobjval()) <= OBJ_RTOL * max(1.0, abs(om.getobjval()))
-    assert abs(m.getobjval() - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+    assert abs(m.getobjval() - om.getobjval()) <= planted_obj_bound(inst)
+    assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
     x = m.getsolution()
     assert max_nl_violation(inst, x) <= 1e-6 * (1 + 1e-6)
     assert np.max(np.abs(x - inst.xhat)) <= 1e-3                      # non-degenerate vertex: x is pinned too
@@ -36,8 +37,8 @@ def test_nonlinear_objective_epigraph_lift():
     assert m.optimize() == "Optimal"
     assert m.num_var == inst.n + 1                                      # model.jl:137-138
     om = oracle_solve_instance(inst)
-    assert abs(m.getobjval() - om.getobjval()) <= OBJ_RTOL * max(1.0, abs(om.getobjval()))
-    assert abs(m.getobjval() - inst.opt_obj) <= 1e-4 * max(1.0, abs(inst.opt_obj))
+    assert abs(m.getobjval() - om.getobjval()) <= planted_obj_bound(inst)
+    assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
 
 
 def test_max_sense():
@@ -46,7 +47,7 @@ def test_max_sense():
     inst.obj_p0 = -inst.obj_p0
     m = hip_load_instance(ktn, inst)
     assert m.optimize() == "Optimal"
-    assert abs(m.getobjval() - (-inst.opt_obj)) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+    assert abs(m.getobjval() - (-inst.opt_obj)) <= planted_obj_bound(inst)
 
 
 def test_iter_cap_gives_userlimit_and_reset_restores_the_loaded_state():
@@ -82,7 +83,7 @@ def test_full_size_cfg3_properties():
     m = hip_load_instance(ktn, inst)
     assert m.optimize() == "Optimal"
     x = m.getsolution()
-    assert abs(m.getobjval() - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+    assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
     assert max_nl_violation(inst, x) <= 1e-6 * (1 + 1e-6)
     assert np.all(x >= inst.l_var - 1e-9) and np.all(x <= inst.u_var + 1e-9)
     # linear rows: the LP tolerance floor is 0.3 f_tol
@@ -105,7 +106,7 @@ def test_batch_throughput_mode_matches_sequential_solves():
     for a, b, inst in zip(seq, par, insts):
         assert a["status"] == b["status"] == "Optimal"
         assert a["objval"] == b["objval"] and a["iters"] == b["iters"] and np.array_equal(a["x"], b["x"])
-        assert abs(a["objval"] - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+        assert abs(a["objval"] - inst.opt_obj) <= planted_obj_bound(inst)
 
 
 def test_cut_pool_purging_keeps_the_answer():
@@ -118,7 +119,7 @@ def test_cut_pool_purging_keeps_the_answer():
     assert purge.optimize() == "Optimal"
     assert purge.stat("purged_rows") > 0 and purge.lp_num_rows() < keep.lp_num_rows()
     assert purge.numcuts() >= purge.lp_num_rows()                       # numcuts stays cumulative (model.jl:333)
-    assert abs(purge.getobjval() - keep.getobjval()) <= OBJ_RTOL * max(1.0, abs(keep.getobjval()))
+    assert abs(purge.getobjval() - keep.getobjval()) <= planted_obj_bound(inst)
     assert max_nl_violation(inst, purge.getsolution()) <= 1e-6 * (1 + 1e-6)
 
 
@@ -130,7 +131,7 @@ def test_full_size_configs_other_seeds(name, seed):
     m = hip_load_instance(ktn, inst)
     assert m.optimize() == "Optimal"
     x = m.getsolution()
-    assert abs(m.getobjval() - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+    assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
     assert max_nl_violation(inst, x) <= 1e-6 * (1 + 1e-6)
     assert np.max(np.abs(x - inst.xhat)) <= 1e-3
 
@@ -143,7 +144,7 @@ def test_fused_batch_mode_solves_every_instance():
     assert len(res) == len(insts)
     for r, inst in zip(res, insts):
         assert r["status"] == "Optimal"
-        assert abs(r["objval"] - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+        assert abs(r["objval"] - inst.opt_obj) <= planted_obj_bound(inst)
         assert max_nl_violation(inst, r["x"]) <= 1e-6 * (1 + 1e-6)
         assert np.max(np.abs(r["x"] - inst.xhat)) <= 1e-3
 
@@ -184,7 +185,7 @@ def test_ecp_with_and_without_cut_selection_reach_the_same_optimum():
         assert max_nl_violation(inst, m.getsolution()) <= 1e-6 + 1e-9
     assert res[0][2] == 0 and res[1][2] >= 1 and res[1][1] < res[0][1]
     assert abs(res[0][0] - res[1][0]) <= 2e-6 * max(1.0, abs(res[0][0]))
-    assert abs(res[1][0] - inst.opt_obj) <= 1e-5 * max(1.0, abs(inst.opt_obj))
+    assert abs(res[1][0] - inst.opt_obj) <= planted_obj_bound(inst)
 
 
 def test_full_size_cfg4_one_million_nonlinear_rows():
@@ -194,7 +195,7 @@ def test_full_size_cfg4_one_million_nonlinear_rows():
     m = hip_load_instance(ktn, inst)
     assert m.optimize() == "Optimal"
     x = m.getsolution()
-    assert abs(m.getobjval() - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+    assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
     assert max_nl_violation(inst, x) <= 1e-6 * (1 + 1e-6)
     assert np.max(np.abs(x - inst.xhat)) <= 1e-3
     assert m.stat("cut_selections") >= 1 and m.stat("purged_rows") > 0
@@ -210,7 +211,7 @@ def test_primal_stagnation_exit_of_the_lp_keeps_the_answer():
         m = hip_load_instance(ktn, inst, lp_stag_factor=f)
         assert m.optimize() == "Optimal"
         x = m.getsolution()
-        assert abs(m.getobjval() - inst.opt_obj) <= OBJ_RTOL * max(1.0, abs(inst.opt_obj))
+        assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
         assert max_nl_violation(inst, x) <= 1e-6 * (1 + 1e-6)
         assert np.max(np.abs(x - inst.xhat)) <= 1e-3
         res[f] = (m.stat("pdhg_iters"), m.stat("lp_stagnation_exits"), m.getobjval())
