@@ -133,8 +133,11 @@ typedef struct {
                                        gap within lp_stag_factor * tolerance (the dual of a degenerate LP crawls long after
                                        the primal has converged), and a row violation that has stalled below 2x the row
                                        tolerance with everything else converged is accepted; 0 = only the full criteria      */
-    int32_t lp_ruiz_warm;   /* 2       Ruiz passes when the scaling of the previous LP solve is reused for all but the appended rows
-                                       (0 = always lp_ruiz_iters passes from scratch)                                         */
+    int32_t lp_ruiz_warm;   /* 0       > 0: reuse the Ruiz equilibration of the previous LP solve for all but the appended rows and run
+                                       only this many passes (measured on cfg3: the different scaling costs 1.8x the PDHG
+                                       iterations, so the default stays lp_ruiz_iters passes from scratch)                    */
+    int64_t lp_tiled_nnz;   /* 4000000 LPs with at least this many non-zeros run their SpMVs from tiled copies of the matrix
+                                       (input vector staged through LDS in 64 KB blocks); 0 = never     */
     /* terminal refinement of small problems: once every NL row is within f_tol (the reference's stop rule, src/model.jl:257,273)
        the loop keeps cutting rows that are beyond polish_factor * f_tol, with the LP solved to the matching tolerance.  The
        reference's exact simplex vertices end Kelley's method far below f_tol on its small test models (its suite asserts the

@@ -226,6 +226,7 @@ struct Engine {
     DBuf<uint64_t> k_in, k_out;
     DBuf<uint32_t> p_in, p_out;
     DBuf<char> d_sorttmp;
+    DBuf<double> dr_r, dc_r;
     DBuf<double> dr, dc, statr, statc, ch, lh, uh, loh, hih, xh, yh, x0h, y0h, xth, yth, xbar, pv, pw, box;
     DBuf<double> partials, chk_part, chkout, power_v;
     // exact small-LP path (dense_lp.hpp)
@@ -239,6 +240,23 @@ struct Engine {
     double omega = 1.0;
     bool have_omega = false;
     int grp_rows = 8, grp_cols = 8;
+    // tiled copies of A^ (outputs = rows) and A^' (outputs = columns) for LPs beyond the caches (kernels.hpp "tiled SpMV")
+    struct TiledBuf {
+        DBuf<int64_t> segstart, segtot;
+        DBuf<uint16_t> bptr, cur, idx;
+        DBuf<int32_t> pcnt;
+        DBuf<double> val;
+        int nb_in = 0;
+        int64_t tiles = 0, grid = 0, pieces = 1;     // persistent grid and the largest number of pieces of a tile
+        TiledMat view() const { return TiledMat{segstart.p, bptr.p, idx.p, val.p, nb_in}; }
+    } tA, tAT;
+    DBuf<double> tpart;
+    bool tiled_on = false;
+    void launch_tiled(const TiledBuf& T, int64_t n_out, int64_t n_in, const double* in, hipEvent_t e0) {
+        hipExtLaunchKernelGGL(k_spmv_tiled, dim3((unsigned)T.grid), dim3(kTileThreads), 0, stream, e0, nullptr, 0, n_out, n_in, T.tiles,
+                              T.view(), in, tpart.p);
+    }
+    bool build_tiled(TiledBuf& T, int64_t n_out, int64_t n_in, const int64_t* ptr, const int32_t* idx, const double* val, int64_t skip_longer);
     int64_t scal_rows = 0, scal_cols = 0;   // dr[0, scal_rows) / dc[0, scal_cols) hold the scaling of the last solve
 
     // ---- run state ----
@@ -1075,10 +1093,10 @@ void Engine::purge_cuts() {
         KTN_HIP(hipMemsetAsync(d_lastcut.p, 0xFF, d_lastcut.n * sizeof(int64_t), stream));
         KTN_HIP(hipMemsetAsync(d_cutprev2.p, 0xFF, (size_t)m_new * sizeof(int64_t), stream));
     }
-    if (scal_rows == m) {                         // keep the row scaling of the surviving rows (warm start of the next solve)
+    if (scal_rows == m && prm.lp_ruiz_warm > 0 && dr_r.n >= (size_t)m) {   // keep the row scaling of the surviving rows (warm start of the next solve)
         statr.resize((size_t)m, stream);
-        LAUNCH_1(k_compact_vec, m, stream, m, d_keep.p, d_newidx.p, dr.p, statr.p);
-        dr.swap(statr);
+        LAUNCH_1(k_compact_vec, m, stream, m, d_keep.p, d_newidx.p, dr_r.p, statr.p);
+        dr_r.swap(statr);
         scal_rows = m_new;
     } else {
         scal_rows = 0;
@@ -1102,11 +1120,17 @@ void Engine::compute_scaling(bool identity) {
     dc.resize((size_t)n_lp, stream);
     statr.resize((size_t)std::max<int64_t>(M, 1), stream);
     statc.resize((size_t)n_lp, stream);
-    // Warm start (lp_ruiz_warm): rows are only ever appended, so dr / dc of the previous solve already equilibrate all but
-    // the new rows.  Those start at 1 and a few Ruiz passes + the final Pock-Chambolle pass (which alone carries the
-    // ||A^||_2 <= 1 guarantee, for any input scaling) replace the 10 passes from scratch.
+    // Warm start (lp_ruiz_warm > 0): rows are only ever appended, so the Ruiz (max-norm) equilibration of the previous solve
+    // -- kept in dr_r / dc_r as it was BEFORE that solve's Pock-Chambolle pass -- already fits all but the new rows.  Those
+    // start at 1 and lp_ruiz_warm passes replace the lp_ruiz_iters passes from scratch; the Pock-Chambolle pass (which
+    // carries the ||A^||_2 <= 1 guarantee) is applied afresh.  (Warm-starting from the FINAL scaling instead compounds the
+    // Pock-Chambolle passes of all earlier solves: cfg3 then needs 3.5x the PDHG iterations.)
     const bool warm = !identity && prm.lp_ruiz_warm > 0 && scal_rows > 0 && scal_rows <= M && scal_cols == n_lp;
+    dr_r.resize((size_t)std::max<int64_t>(M, 1), stream);
+    dc_r.resize((size_t)n_lp, stream);
     if (warm) {
+        KTN_HIP(hipMemcpyAsync(dr.p, dr_r.p, (size_t)scal_rows * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        KTN_HIP(hipMemcpyAsync(dc.p, dc_r.p, (size_t)n_lp * sizeof(double), hipMemcpyDeviceToDevice, stream));
         LAUNCH_1(k_fill, M - scal_rows, stream, M - scal_rows, dr.p + scal_rows, 1.0);
         stats["lp_scaling_warm"] += 1.0;
     } else {
@@ -1119,6 +1143,10 @@ void Engine::compute_scaling(bool identity) {
         const int passes = warm ? prm.lp_ruiz_warm : prm.lp_ruiz_iters;
         for (int it = 0; it <= passes; ++it) {
             const int mode = (it == passes) ? 1 : 0;   // last pass: Pock-Chambolle (alpha = 1)
+            if (mode == 1 && prm.lp_ruiz_warm > 0) {
+                KTN_HIP(hipMemcpyAsync(dr_r.p, dr.p, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                KTN_HIP(hipMemcpyAsync(dc_r.p, dc.p, (size_t)n_lp * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            }
             LAUNCH_G(gr, k_scale_stat, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, mode, statr.p);
             LAUNCH_G(gc, k_scale_stat, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, statc.p);
             LAUNCH_1(k_scale_apply2, std::max(M, n_lp), stream, M, dr.p, statr.p, n_lp, dc.p, statc.p);
@@ -1131,6 +1159,51 @@ void Engine::compute_scaling(bool identity) {
     LAUNCH_G(gr, k_scale_vals, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, r_sval.p);
     LAUNCH_G(gc, k_scale_vals, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, c_sval.p);
     check_launch();
+}
+
+// Tiled copy of a sparse matrix given by (ptr, idx, val) over n_out outputs and n_in inputs; outputs longer than
+// skip_longer are left out (long rows have their own kernel).  Returns false when a (tile, block) segment does not fit
+// the 16-bit offsets (then the CSR kernels serve this solve).
+bool Engine::build_tiled(TiledBuf& T, int64_t n_out, int64_t n_in, const int64_t* ptr, const int32_t* idx, const double* val,
+                         int64_t skip_longer) {
+    T.tiles = ceil_div(n_out, kTileOut);
+    T.nb_in = ceil_div(n_in, kTileIn);
+    const size_t cells = (size_t)T.tiles * (size_t)T.nb_in;
+    T.bptr.resize(cells * (kTileOut + 1), stream);
+    T.cur.resize(cells * (kTileOut + 1), stream);
+    T.bptr.zero(stream);
+    T.cur.zero(stream);
+    T.segtot.resize(cells + 1, stream);
+    T.segstart.resize(cells + 1, stream);
+    T.segtot.zero(stream);
+    KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
+    LAUNCH_1(k_tile_count, n_out, stream, n_out, ptr, idx, T.nb_in, skip_longer, T.bptr.p, d_anynf.p + 1);
+    hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)cells), dim3(kTileThreads), 0, stream, T.bptr.p, T.segtot.p, d_anynf.p + 1);
+    check_launch();
+    exclusive_scan(T.segtot.p, T.segstart.p, cells + 1);
+    T.idx.resize((size_t)NNZ + 1, stream);
+    T.val.resize((size_t)NNZ + 1, stream);
+    LAUNCH_1(k_tile_fill, n_out, stream, n_out, ptr, idx, val, T.nb_in, skip_longer, T.bptr.p, T.cur.p, T.segstart.p, T.idx.p, T.val.p);
+    check_launch();
+    int32_t ovf = 0;
+    KTN_HIP(hipMemcpyAsync(&ovf, d_anynf.p + 1, 4, hipMemcpyDeviceToHost, stream));
+    sync();
+    // two 1024-thread workgroups per CU (80 KB of LDS each): a persistent grid over the (tile, block) units
+    const int64_t U = T.tiles * T.nb_in;
+    static const int wg_per_cu = std::getenv("KTN_TILED_WG") ? std::atoi(std::getenv("KTN_TILED_WG")) : 2;
+    T.grid = std::max<int64_t>(std::min<int64_t>((int64_t)wg_per_cu * num_cus, U), 1);
+    {
+        std::vector<int32_t> pc((size_t)T.tiles);
+        T.pieces = 1;
+        for (int64_t tl = 0; tl < T.tiles; ++tl) {       // owner(u) = ((u + 1) G - 1) / U, as in the kernel
+            const int64_t p0 = ((tl * T.nb_in + 1) * T.grid - 1) / U, p1 = (((tl + 1) * T.nb_in) * T.grid - 1) / U;
+            pc[(size_t)tl] = (int32_t)(p1 - p0 + 1);
+            T.pieces = std::max<int64_t>(T.pieces, p1 - p0 + 1);
+        }
+        T.pcnt.upload(pc, stream);
+        sync();
+    }
+    return ovf == 0;
 }
 
 void Engine::find_long_rows() {
@@ -1162,8 +1235,16 @@ void Engine::find_long_rows() {
 void Engine::launch_y(const SpMat& A, double sigma, double w, double rho, hipEvent_t e0, hipEvent_t e1) {
     const int64_t m = M;
     const int64_t thr = n_long > 0 ? kLongRow : (int64_t)1 << 62;
-    if (e0) LAUNCH_G_EV(grp_rows, k_pdhg_y, m, stream, e0, e1, m, A, xbar.p, yh.p, y0h.p, loh.p, hih.p, sigma, w, rho, thr);
-    else LAUNCH_G(grp_rows, k_pdhg_y, m, stream, m, A, xbar.p, yh.p, y0h.p, loh.p, hih.p, sigma, w, rho, thr);
+    if (tiled_on && m > 0) {
+        launch_tiled(tA, m, n_lp, xbar.p, e0);
+        hipExtLaunchKernelGGL(k_y_epilogue, dim3(ceil_div(m, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, m, tA.pcnt.p,
+                              tpart.p, (n_long > 0 ? A.ptr : (const int64_t*)nullptr), thr, yh.p, y0h.p,
+                              loh.p, hih.p, sigma, w, rho);
+    } else if (e0) {
+        LAUNCH_G_EV(grp_rows, k_pdhg_y, m, stream, e0, e1, m, A, xbar.p, yh.p, y0h.p, loh.p, hih.p, sigma, w, rho, thr);
+    } else {
+        LAUNCH_G(grp_rows, k_pdhg_y, m, stream, m, A, xbar.p, yh.p, y0h.p, loh.p, hih.p, sigma, w, rho, thr);
+    }
     if (n_long > 0)
         hipLaunchKernelGGL((k_pdhg_y_long<false>), dim3((unsigned)n_long), dim3(kLongBlock), 0, stream, d_longrows.p, A, xbar.p,
                            (const double*)nullptr, yh.p, y0h.p, yth.p, loh.p, hih.p, dr.p, sigma, w, rho, (double*)nullptr);
@@ -1171,8 +1252,15 @@ void Engine::launch_y(const SpMat& A, double sigma, double w, double rho, hipEve
 void Engine::launch_x(const SpMat& AT, double tau, double w, double rho, bool update, hipEvent_t e0, hipEvent_t e1) {
     const int64_t n = n_lp;
     if (update) {
-        if (e0) LAUNCH_GB_EV(grp_cols, k_pdhg_x, true, n, stream, e0, e1, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
-        else LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        if (tiled_on && M > 0) {
+            launch_tiled(tAT, n, M, yh.p, e0);
+            hipExtLaunchKernelGGL(k_x_epilogue, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, n, tAT.pcnt.p,
+                                  tpart.p, xh.p, x0h.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        } else if (e0) {
+            LAUNCH_GB_EV(grp_cols, k_pdhg_x, true, n, stream, e0, e1, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        } else {
+            LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        }
     } else {
         LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
     }
@@ -1314,6 +1402,22 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     SpMat A{lp_rowptr.p, lp_col.p, r_sval.p};
     SpMat AT{c_ptr.p, c_row.p, c_sval.p};
     find_long_rows();
+    // LPs beyond the caches: tiled copies of A^ and A^' (kernels.hpp "tiled SpMV"); the check iterations (1 in 64) and the
+    // power iteration keep the CSR / CSC kernels
+    {
+        static const char* tenv = std::getenv("KTN_TILED");
+        tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn;
+        if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0;
+        if (tiled_on) {
+            auto tt = std::chrono::steady_clock::now();
+            tiled_on = build_tiled(tA, M, n_lp, lp_rowptr.p, lp_col.p, r_sval.p, kLongRow) &&
+                       build_tiled(tAT, n_lp, M, c_ptr.p, c_row.p, c_sval.p, (int64_t)1 << 62);
+            tpart.resize((size_t)std::max<int64_t>(tA.pieces * M, tAT.pieces * n_lp), stream);
+            stats["lp_tiled_builds"] += 1.0;
+            stats["lp_tiled_build_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - tt).count();
+            if (!tiled_on) stats["lp_tiled_overflows"] += 1.0;
+        }
+    }
 
     // Step size eta = 0.998 / sigma_max(A^).  sigma_max comes from 20 power iterations (hashed start
     // vector: a constant one can be orthogonal to every row).  The power iteration approaches sigma_max
@@ -1583,13 +1687,41 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
     KTN_HIP(hipMemcpyAsync(x0h.p, xh.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     if (m > 0) KTN_HIP(hipMemcpyAsync(y0h.p, yh.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
     find_long_rows();
+    // LPs beyond the caches: tiled copies of A^ and A^' (kernels.hpp "tiled SpMV"); the check iterations (1 in 64) and the
+    // power iteration keep the CSR / CSC kernels
+    {
+        static const char* tenv = std::getenv("KTN_TILED");
+        tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn;
+        if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0;
+        if (tiled_on) {
+            auto tt = std::chrono::steady_clock::now();
+            tiled_on = build_tiled(tA, M, n_lp, lp_rowptr.p, lp_col.p, r_sval.p, kLongRow) &&
+                       build_tiled(tAT, n_lp, M, c_ptr.p, c_row.p, c_sval.p, (int64_t)1 << 62);
+            tpart.resize((size_t)std::max<int64_t>(tA.pieces * M, tAT.pieces * n_lp), stream);
+            stats["lp_tiled_builds"] += 1.0;
+            stats["lp_tiled_build_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - tt).count();
+            if (!tiled_on) stats["lp_tiled_overflows"] += 1.0;
+        }
+    }
     const double tau = eta / omega_, sigma = eta * omega_;
+    const double ky_bytes = (double)NNZ * 12 + 8.0 * (m + 1) + 8.0 * 5 * m + 8.0 * n;
+    const double kx_bytes = (double)NNZ * 12 + 8.0 * (n + 1) + 8.0 * 7 * n + 8.0 * m;
     for (int64_t k = 0; k < iters; ++k) {
         const double w = (double)(k + 1) / (double)(k + 2);
-        launch_x(AT, tau, w, 1.0, true, nullptr, nullptr);
-        launch_y(A, sigma, w, 1.0, nullptr, nullptr);
-        if ((k & 255) == 255) sync();
+        if (prm.profile) {
+            const size_t e0 = ev_get(), e1 = ev_get(), e2 = ev_get(), e3 = ev_get();
+            launch_x(AT, tau, w, 1.0, true, ev_pool[e0], ev_pool[e1]);
+            launch_y(A, sigma, w, 1.0, ev_pool[e2], ev_pool[e3]);
+            ev_recs.push_back({0, e0, e1, kx_bytes});
+            if (m > 0) ev_recs.push_back({1, e2, e3, ky_bytes});
+        } else {
+            launch_x(AT, tau, w, 1.0, true, nullptr, nullptr);
+            launch_y(A, sigma, w, 1.0, nullptr, nullptr);
+        }
+        if ((k & 255) == 255) { sync(); if (prm.profile) ev_flush(); }
     }
+    sync();
+    if (prm.profile) ev_flush();
     check_launch();
     KTN_HIP(hipMemcpyAsync(x_out, xh.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));
     if (m > 0) KTN_HIP(hipMemcpyAsync(y_out, yh.p, m * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1821,7 +1953,7 @@ void ktn_default_params(ktn_params* p) {
     p->lp_dense_after = 5000;
     p->cut_cap_factor = 2.0; p->cut_cap_min = 10000;
     p->lp_stag_factor = 100.0;
-    p->lp_ruiz_warm = 2;
+    p->lp_ruiz_warm = 0; p->lp_tiled_nnz = 4000000;
     p->polish_factor = 1e-3; p->polish_max_var = 32; p->polish_max_iter = 30;
 }
 

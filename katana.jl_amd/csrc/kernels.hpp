@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "../../include/katana_hip.h"
 
@@ -893,6 +894,270 @@ __global__ __launch_bounds__(kBlock) void k_chk_cols(int64_t n, SpMat AT, const 
         else if (r0 < 0.0) { if (isfinite(uj)) { a.s[10] += uj * r0; a.s[11] += fabs(uj * r0); } else a.s[14] = fmax(a.s[14], -r0); }
     }
     chk_block_store<kBlock>(a, partials);
+}
+
+// ================================================== LP: tiled SpMV for LPs beyond the caches =========================
+// (DESIGN.md section 4 "HBM-regime SpMV".)  In CSR form every 8-byte gather of the input vector is its own L1 miss and
+// drags a 128-byte line from L2; with tens of millions of entries that traffic, not the 12 B/entry matrix stream, is
+// what the kernel waits for (measured: 20 % of the HBM peak).  The tiled form cuts the INPUT index range into blocks of
+// kTileIn entries (64 KB of doubles: one LDS image) and the OUTPUT index range into tiles of kTileOut (one output per
+// thread of a 1024-thread workgroup).  A workgroup owns one output tile (and one of S ranges of input blocks): for each
+// input block it stages the block in LDS, then every thread walks the entries of ITS output that fall into the block --
+// stored contiguously per (tile, block), output after output, as (uint16 local input index, f64 value): 10 B per entry
+// instead of 12 -- and gathers from LDS.  Sums keep a fixed order (block after block, entries in storage order), so
+// results stay bitwise reproducible.  The same kernel serves A x (outputs = rows, from the CSR copy) and A'y (outputs =
+// columns, from the CSC mirror); partial sums of the S ranges are added in order by the step's epilogue kernel.
+constexpr int kTileThreads = 1024;
+constexpr int kTilePer = 4;                              // outputs per thread
+constexpr int kTileOut = kTileThreads * kTilePer;        // outputs per tile
+constexpr int kTileIn = 8192;
+
+struct TiledMat {
+    const int64_t* segstart;   // [tiles * nb_in + 1] first entry of (tile, block)
+    const uint16_t* bptr;      // [tiles * nb_in * (kTileOut + 1)] entry offsets of the tile's outputs inside (tile, block)
+    const uint16_t* idx;       // local input index
+    const double* val;         // scaled values
+    int nb_in;                 // input blocks
+};
+
+// Per input block the workgroup (a) stages the block of the input vector in LDS, (b) multiplies the segment's entries
+// with their LDS-gathered inputs ENTRY-parallel -- thread t takes entries t, t + 1024, ...: perfectly coalesced, eight
+// independent loads per array and lane in flight, no divergence over row lengths -- leaving the products in an LDS chunk,
+// and (c) adds up each output's products OUTPUT-parallel from LDS (thread t owns the outputs t, t + 1024, ... of the
+// tile; a cell holds 2-3 entries on the cut matrices).  (An earlier form walked each output's entries straight from
+// global memory: its divergent, dependent tail loads left the kernel latency-bound at 27 % of the HBM peak.)
+constexpr int kTileChunk = 2048;                         // products per LDS chunk (16 KB): 80 KB of LDS per workgroup, two per CU
+constexpr int kTileCE = kTileChunk / kTileThreads;       // entries per lane and chunk
+// The (tile, block) units, tile-major, are dealt out to the persistent grid in contiguous, equal ranges (two workgroups per
+// CU whatever the number of tiles); a tile's partial sums come from the consecutive workgroups whose ranges touch it
+// ("pieces") and are added in that order by the epilogue.
+__device__ __forceinline__ int64_t tile_unit_begin(int64_t w, int64_t U, int64_t G) { return w * U / G; }
+__device__ __forceinline__ int64_t tile_unit_owner(int64_t u, int64_t U, int64_t G) { return ((u + 1) * G - 1) / U; }
+
+constexpr int kTileRing = 4;                             // sub-chunks requested ahead of their use (register ring)
+
+// position in the WG's stream of sub-chunks: unit u, first entry ch of the sub-chunk inside the unit's segment
+struct TileCursor {
+    int64_t u, seg;
+    int ch, nseg;
+    __device__ __forceinline__ void open(const int64_t* __restrict__ segstart, int64_t u_, int64_t u_end) {
+        u = u_; ch = 0;
+        if (u < u_end) { seg = segstart[u]; nseg = (int)(segstart[u + 1] - seg); } else { seg = 0; nseg = 0; }
+    }
+    // every unit has at least one (possibly empty) sub-chunk
+    __device__ __forceinline__ void next(const int64_t* __restrict__ segstart, int64_t u_end) {
+        ch += kTileChunk;
+        if (ch >= nseg) open(segstart, u + 1, u_end);
+    }
+};
+
+// The matrix entries of a workgroup's unit range are ONE contiguous stream (units are stored tile-major); it is consumed
+// in sub-chunks of kTileChunk entries that never straddle a unit.  A ring of kTileRing register slots keeps the next
+// sub-chunks' loads in flight (issued right after a slot's products are written), so the ~2 us HBM latency is covered by
+// four sub-steps of work instead of stalling every one of them.
+__global__ __launch_bounds__(kTileThreads, 8) void k_spmv_tiled(int64_t n_out, int64_t n_in, int64_t tiles, TiledMat Tm,
+                                                                const double* __restrict__ in, double* __restrict__ part) {
+    __shared__ double xs[kTileIn];
+    __shared__ double prod[kTileChunk];
+    const int64_t U = tiles * Tm.nb_in, G = gridDim.x, w = blockIdx.x;
+    const int64_t u_beg = tile_unit_begin(w, U, G), u_end = tile_unit_begin(w + 1, U, G);
+    if (u_beg >= u_end) return;
+    const int t = threadIdx.x;
+    double acc[kTilePer];
+    int64_t cur = -1;
+    double rv[kTileRing][kTileCE];
+    int rix[kTileRing][kTileCE];
+    TileCursor pf, cs;
+    pf.open(Tm.segstart, u_beg, u_end);
+    cs.open(Tm.segstart, u_beg, u_end);
+    auto request = [&](auto slot_c) {                     // loads of the sub-chunk at the prefetch cursor into ring slot `slot`
+        constexpr int slot = decltype(slot_c)::value;
+        const bool live = pf.u < u_end;
+#pragma unroll
+        for (int i = 0; i < kTileCE; ++i) {
+            const int e = pf.ch + i * kTileThreads + t;
+            const bool on = live && e < pf.nseg;
+            rv[slot][i] = on ? Tm.val[pf.seg + e] : 0.0;
+            rix[slot][i] = on ? (int)Tm.idx[pf.seg + e] : 0;
+        }
+        if (live) pf.next(Tm.segstart, u_end);
+    };
+    request(std::integral_constant<int, 0>{});
+    request(std::integral_constant<int, 1>{});
+    request(std::integral_constant<int, 2>{});
+    request(std::integral_constant<int, 3>{});
+    uint32_t ee[kTilePer];                                // (first entry | end entry << 16) of this thread's outputs in the unit
+    auto flush = [&]() {
+        const int64_t piece = w - tile_unit_owner(cur * Tm.nb_in, U, G);
+#pragma unroll
+        for (int k = 0; k < kTilePer; ++k) {
+            const int64_t o = cur * kTileOut + k * kTileThreads + t;
+            if (o < n_out) part[piece * n_out + o] = acc[k];
+        }
+    };
+    auto step = [&](auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        if (cs.ch == 0) {                                 // first sub-chunk of unit cs.u: stage its block of the input vector
+            const int64_t tile = cs.u / Tm.nb_in;
+            const int b = (int)(cs.u - tile * Tm.nb_in);
+            if (tile != cur) {
+                if (cur >= 0) flush();
+                cur = tile;
+#pragma unroll
+                for (int k = 0; k < kTilePer; ++k) acc[k] = 0.0;
+            }
+            // xs is only read between the two barriers of a sub-step, so it is free here
+            const int64_t c0 = (int64_t)b * kTileIn;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                                // two batches of four loads in flight (register budget: 64)
+                double xf[kTileIn / kTileThreads / 2];
+#pragma unroll
+                for (int i = 0; i < kTileIn / kTileThreads / 2; ++i) {
+                    const int64_t c = c0 + (h * 4 + i) * kTileThreads + t;
+                    xf[i] = in[c < n_in ? c : n_in - 1];
+                }
+#pragma unroll
+                for (int i = 0; i < kTileIn / kTileThreads / 2; ++i)
+                    xs[(h * 4 + i) * kTileThreads + t] = (c0 + (h * 4 + i) * kTileThreads + t < n_in) ? xf[i] : 0.0;
+            }
+            const uint16_t* bp = Tm.bptr + cs.u * (kTileOut + 1);
+            uint16_t q0[kTilePer], q1[kTilePer];
+#pragma unroll
+            for (int k = 0; k < kTilePer; ++k) { q0[k] = bp[k * kTileThreads + t]; q1[k] = bp[k * kTileThreads + t + 1]; }
+#pragma unroll
+            for (int k = 0; k < kTilePer; ++k) ee[k] = (uint32_t)q0[k] | ((uint32_t)q1[k] << 16);
+        }
+        __syncthreads();                                  // xs staged; products of the previous sub-step consumed
+#pragma unroll
+        for (int i = 0; i < kTileCE; ++i) prod[i * kTileThreads + t] = rv[slot][i] * xs[rix[slot][i]];
+        request(slot_c);                                  // the slot is free: next sub-chunk, kTileRing sub-steps ahead
+        __syncthreads();
+        const int ch = cs.ch;
+#pragma unroll
+        for (int k = 0; k < kTilePer; ++k) {
+            const int e0 = (int)(ee[k] & 0xFFFFu), e1 = (int)(ee[k] >> 16);
+            const int lo = e0 > ch ? e0 : ch;
+            const int hi = e1 < ch + kTileChunk ? e1 : ch + kTileChunk;
+            for (int e = lo; e < hi; ++e) acc[k] += prod[e - ch];
+        }
+        cs.next(Tm.segstart, u_end);
+    };
+    while (cs.u < u_end) {
+        step(std::integral_constant<int, 0>{});
+        if (cs.u >= u_end) break;
+        step(std::integral_constant<int, 1>{});
+        if (cs.u >= u_end) break;
+        step(std::integral_constant<int, 2>{});
+        if (cs.u >= u_end) break;
+        step(std::integral_constant<int, 3>{});
+    }
+    if (cur >= 0) flush();
+}
+
+// sum of the pieces of output o, in piece order (pcnt[tile] = number of workgroups whose unit range touches the tile)
+__device__ __forceinline__ double tile_pieces_sum(const double* __restrict__ part, int64_t o, int64_t n_out, const int32_t* __restrict__ pcnt) {
+    const int np = pcnt[o / kTileOut];
+    double acc = 0.0;
+    for (int p = 0; p < np; ++p) acc += part[(int64_t)p * n_out + o];
+    return acc;
+}
+// epilogues of the tiled steps: the pieces in order, then exactly the arithmetic of k_pdhg_x / k_pdhg_y
+__global__ __launch_bounds__(kBlock) void k_x_epilogue(int64_t n, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
+                                                       double* __restrict__ x, const double* __restrict__ x0, double* __restrict__ xbar,
+                                                       const double* __restrict__ c, const double* __restrict__ l,
+                                                       const double* __restrict__ u, double tau, double w, double rho) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    const double xv = x[j], cj = c[j], lj = l[j], uj = u[j], x0j = x0[j];
+    const double acc = tile_pieces_sum(part, j, n, pcnt);
+    const double xtv = clampd(xv - tau * (cj - acc), lj, uj);
+    xbar[j] = 2.0 * xtv - xv;
+    x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0j;
+}
+__global__ __launch_bounds__(kBlock) void k_y_epilogue(int64_t m, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
+                                                       const int64_t* __restrict__ rowptr, int64_t long_thresh, double* __restrict__ y,
+                                                       const double* __restrict__ y0, const double* __restrict__ lo,
+                                                       const double* __restrict__ hi, double sigma, double w, double rho) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    if (rowptr && rowptr[i + 1] - rowptr[i] > long_thresh) return;      // served by k_pdhg_y_long (rowptr == NULL: no long rows)
+    const double yv = y[i], loi = lo[i], hii = hi[i], y0i = y0[i];
+    const double acc = tile_pieces_sum(part, i, m, pcnt);
+    const double v = yv - sigma * acc;
+    const double ytv = v + sigma * clampd(-v / sigma, loi, hii);
+    y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0i;
+}
+
+// ---- building the tiled copy (once per LP solve, after the scaling): count -> scan per (tile, block) -> fill ----------
+// cnt is zeroed, shaped like bptr; thread o owns the shorts [.. + t + 1] of its tile's blocks (no atomics needed)
+__global__ __launch_bounds__(kBlock) void k_tile_count(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                       int nb_in, int64_t skip_longer, uint16_t* __restrict__ cnt,
+                                                       int32_t* __restrict__ overflow) {
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (o >= n_out) return;
+    const int64_t beg = ptr[o], end = ptr[o + 1];
+    if (end - beg > skip_longer) return;
+    const int64_t tile = o / kTileOut;
+    const int t = (int)(o - tile * kTileOut);
+    for (int64_t e = beg; e < end; ++e) {
+        const int b = idx[e] / kTileIn;
+        uint16_t* p = cnt + ((tile * nb_in + b) * (kTileOut + 1) + t + 1);
+        const uint16_t c = *p;
+        if (c == 0xFFFF) { atomicOr(overflow, 1); return; }
+        *p = (uint16_t)(c + 1);
+    }
+}
+// one workgroup per (tile, block): in-place inclusive scan of the kTileOut counts -> offsets; segment total out.
+// Thread t scans the kTilePer CONSECUTIVE counts [t * kTilePer, (t + 1) * kTilePer), then the thread totals are scanned.
+__global__ __launch_bounds__(kTileThreads) void k_tile_scan(uint16_t* __restrict__ cnt, int64_t* __restrict__ segtot,
+                                                            int32_t* __restrict__ overflow) {
+    __shared__ uint32_t wsum[kTileThreads / 64];
+    const int64_t tb = blockIdx.x;
+    uint16_t* p = cnt + tb * (kTileOut + 1);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t c[kTilePer];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < kTilePer; ++k) { tot += p[t * kTilePer + k + 1]; c[k] = tot; }
+    uint32_t v = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(v, off, 64);
+        if (lane >= off) v += u;
+    }
+    if (lane == 63) wsum[wv] = v;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int k = 0; k < wv; ++k) base += wsum[k];
+    v += base;                      // inclusive over threads
+    const uint32_t excl = v - tot;
+    if (v > 0xFFFFu) atomicOr(overflow, 1);
+#pragma unroll
+    for (int k = 0; k < kTilePer; ++k) p[t * kTilePer + k + 1] = (uint16_t)(excl + c[k]);
+    if (t == kTileThreads - 1) segtot[tb] = (int64_t)v;
+}
+__global__ __launch_bounds__(kBlock) void k_tile_fill(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                      const double* __restrict__ val, int nb_in, int64_t skip_longer,
+                                                      const uint16_t* __restrict__ bptr, uint16_t* __restrict__ cur,
+                                                      const int64_t* __restrict__ segstart, uint16_t* __restrict__ tidx,
+                                                      double* __restrict__ tval) {
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (o >= n_out) return;
+    const int64_t beg = ptr[o], end = ptr[o + 1];
+    if (end - beg > skip_longer) return;
+    const int64_t tile = o / kTileOut;
+    const int t = (int)(o - tile * kTileOut);
+    for (int64_t e = beg; e < end; ++e) {
+        const int c = idx[e];
+        const int b = c / kTileIn;
+        const int64_t tb = tile * nb_in + b;
+        uint16_t* q = cur + (tb * (kTileOut + 1) + t);
+        const uint16_t k = *q;
+        *q = (uint16_t)(k + 1);
+        const int64_t pos = segstart[tb] + bptr[tb * (kTileOut + 1) + t] + k;
+        tidx[pos] = (uint16_t)(c - b * kTileIn);
+        tval[pos] = val[e];
+    }
 }
 
 // ---------------------------------------------------------- diagonal scaling ------

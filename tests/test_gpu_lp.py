@@ -186,7 +186,7 @@ def test_exact_lp_reproduces_the_simplex_trajectory(kid):
     from kat_util import load_kats
     k = [m for m in load_kats() if m["id"] == kid][0]
     om = oracle_solve_kat(k)
-    M = hip_model_from_kat(ktn, k, lp_dense_after=-1)
+    M = hip_model_from_kat(ktn, k, lp_dense_after=-1, polish_factor=0.0)      # the reference's loop, nothing after the stop rule
     assert M.solve() == om.status == "Optimal"
     assert M.internal_model.numiters() == om.numiters()
     assert abs(M.getobjectivevalue() - om.getobjval()) <= 1e-7
@@ -203,3 +203,31 @@ def test_stalled_first_order_lp_hands_over_to_the_exact_kernel():
     im = M.internal_model
     assert im.stat("lp_stalls") >= 1 and im.stat("dense_lp_solves") >= 1
     assert isapprox(M.getobjectivevalue(), k["expect"]["obj"], 1e-6, 1e-6)
+
+
+def test_tiled_spmv_steps_match_the_csr_steps():
+    """LPs beyond the caches run k_pdhg_x / k_pdhg_y from tiled copies of the matrix (input staged through LDS, kernels.hpp
+    "tiled SpMV"): the same PDHG iterates as the CSR kernels up to the summation order, and the same ECP answer"""
+    import numpy as np
+    from helpers import hip_load_instance, max_nl_violation, planted_obj_bound
+    inst = ktn.instances.make_instance(n=20000, m_nl=60000, k=24, family="explog", seed=5)
+    out = {}
+    for name, thr in (("csr", 0), ("tiled", 1)):
+        m = hip_load_instance(ktn, inst, lp_tiled_nnz=thr, cut_cap_factor=0.0, purge_age=0)
+        sep = ktn.KatanaHipSeparator(m); sep.initialize()
+        sep.precompute(np.clip(inst.xhat + 2.0, inst.l_var, inst.u_var))
+        nviol, _ = sep.sweep(1e-6)
+        assert m.lp_num_rows() > 2 * 8192
+        rng = np.random.default_rng(1)
+        x0, y0 = rng.uniform(-1, 1, m.num_var), np.abs(rng.standard_normal(m.lp_num_rows()))
+        _, _, _, lo, hi = m.lp_rows()
+        y0 = np.where(np.isfinite(lo), y0, -y0)                      # sign-feasible duals
+        out[name] = m.lp_pdhg_raw(x0, y0, 2e-3, 1.0, 40) + (m.stat("lp_tiled_builds"),)
+    assert out["csr"][2] == 0 and out["tiled"][2] == 1
+    for a, b in zip(out["csr"][:2], out["tiled"][:2]):
+        assert np.max(np.abs(a - b)) <= 1e-11 * max(1.0, np.max(np.abs(a)))
+    # whole solve through the tiled path
+    m = hip_load_instance(ktn, inst, lp_tiled_nnz=1, cut_cap_factor=0.0, purge_age=0)
+    assert m.optimize() == "Optimal" and m.stat("lp_tiled_builds") >= 1
+    assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
+    assert max_nl_violation(inst, m.getsolution()) <= 1e-6 * (1 + 1e-6)
