@@ -11,15 +11,23 @@ f_tol) the engine is reset to its post-loadproblem! state and the next step star
 so K steps are K consecutive iterations of back-to-back solves.  Inputs are resident in HBM before
 the timed region (ktn_loadproblem copies them once).
 
+With --gpus N > 1 (one rank per GPU, torch.distributed.run) the workload is BASELINE.json configs[3] ("cfg4": 1e6
+exp/log rows) with the LP ROW-SHARDED over the ranks (katana.jl_amd/distributed.py::RowShardedKatanaModel): every rank
+sweeps its block of NL rows and keeps its own cuts, A'y costs one RCCL all-reduce of an n-vector per PDHG iteration.
+The line then also carries the per-phase split and, for the strong-scaling ratio, the same workload timed on rank 0's
+GPU alone in the same run.
+
 Prints ONE JSON line (rank 0).  `value` = ECP iterations / second, whole job.
-  roofline     -- the dominant kernel (k_pdhg_y: the A x SpMV + dual prox of the GPU LP), algorithmic
-                  bytes per launch / mean launch duration from the start/stop hipEvents of
-                  hipExtLaunchKernelGGL on the engine's own stream, in a second, identical pass over the
-                  same K steps (profile=1).
+  roofline     -- the dominant kernel = whichever of k_pdhg_x / k_pdhg_y has the larger total time in the run
+                  (algorithmic bytes per launch / mean launch duration from the start/stop hipEvents of
+                  hipExtLaunchKernelGGL on the engine's own stream, in a second, identical pass over the same K steps
+                  with profile=1); the other LP kernel and the sweep kernel are listed under other_kernels.
   sweep_roofline -- the separator sweep (k_sep_eval_blk + k_sep_combine) on the HBM-resident variant of the workload
                   (cfg3_hbm: 2048 instead of 32 entries per NL row, 411 MB per pass), same timing.
-  cpu_baseline -- the CPU oracle (serial restatement of the reference + HiGHS dual simplex, 1 core)
-                  on a bounded sample: the same family at half scale, full solve to f_tol.
+  spmv_roofline -- the LP SpMV steps on an HBM-resident cut matrix (cfg4's LP after one un-capped sweep: >= 1.2e7
+                  non-zeros, CSR + CSC mirror beyond the Infinity Cache), same timing.
+  cpu_baseline -- the CPU oracle (serial restatement of the reference + HiGHS dual simplex, 1 core) on the SAME
+                  configuration as `value` (full cfg3: one solve to f_tol, about 100 s of one host core).
 """
 import argparse
 import json
@@ -40,12 +48,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=33)
     ap.add_argument("--warmup", type=int, default=11)
-    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--workload", default=None, help="default: cfg3 on one GPU, cfg4 on several")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sweep-roofline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-spmv-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-scale", type=float, default=1.0, help="1.0 = the configuration of `value`; 0.5 = half scale (quick)")
+    ap.add_argument("--replicated-lp", action="store_true", help="N > 1: the round-1 design (replicated LP, all-gather of cuts)")
+    a = ap.parse_args()
+    if a.workload is None:
+        a.workload = "cfg3" if a.gpus == 1 else "cfg4"
+    return a
 
 
 def run_steps(model, nsteps, solve_log=None):
@@ -74,8 +88,8 @@ def cpu_baseline(args):
     from oracle.evaluators import SeparableNLPEvaluator
     from oracle.katana import KatanaModelParams, KatanaNonlinearModel as OracleModel
     cfg = dict(ktn.instances.CONFIGS[args.workload])
-    cfg["n"] //= 2
-    cfg["m_nl"] //= 2
+    cfg["n"] = int(cfg["n"] * args.cpu_baseline_scale)
+    cfg["m_nl"] = int(cfg["m_nl"] * args.cpu_baseline_scale)
     inst = ktn.instances.make_instance(seed=args.seed, **cfg)
     d = SeparableNLPEvaluator(inst.n, inst.rowptr, inst.col, inst.kind, inst.p0, inst.p1, inst.rconst, inst.obj_col,
                               inst.obj_kind, inst.obj_p0, inst.obj_p1, inst.obj_const)
@@ -95,9 +109,11 @@ def cpu_baseline(args):
     gwall = time.perf_counter() - t0
     return {
         "value": om.numiters() / wall, "unit": "ECP iterations/s", "cores": 1, "kind": "port",
-        "sample": "%s family at half scale (n=%d, m_lin=%d, m_nl=%d, k=%d, seed %d): one full solve to f_tol=1e-6; "
+        "sample": "%s %s (n=%d, m_lin=%d, m_nl=%d, k=%d, seed %d): one full solve to f_tol=1e-6; "
                   "oracle = serial CPU restatement of src/model.jl:219-319 + HiGHS dual simplex (SciPy 1.15.3), "
-                  "warm-started, 1 thread" % (args.workload, inst.n, inst.m_lin, inst.m_nl, cfg["k"], args.seed),
+                  "warm-started, 1 thread" % (args.workload, "at full size: the configuration of `value`" if args.cpu_baseline_scale == 1.0
+                                              else "family at scale %g" % args.cpu_baseline_scale, inst.n, inst.m_lin, inst.m_nl,
+                                              cfg["k"], args.seed),
         "status": status, "ecp_iters": om.numiters(), "wall_s": wall, "obj": om.getobjval(), "planted_obj": inst.opt_obj,
         "host_cores_available": os.cpu_count(),
         "gpu_on_same_sample": {"value": m.numiters() / gwall, "wall_s": gwall, "ecp_iters": m.numiters(),
@@ -130,9 +146,12 @@ def main():
             dist.init_process_group(backend)
 
     inst = ktn.instances.make_config(args.workload, seed=args.seed)
-    if world > 1:
+    if world > 1 and args.replicated_lp:
         from katana_jl_amd.distributed import ShardedKatanaModel
         model = ShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=local_rank), inst, rank, world, dist)
+    elif world > 1:
+        from katana_jl_amd.distributed import RowShardedKatanaModel
+        model = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=local_rank), inst, rank, world, dist)
     else:
         model = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, device=local_rank))
         model.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense,
@@ -146,12 +165,14 @@ def main():
     run_steps(model, args.warmup)
     barrier()
     solves = []
-    p0 = model.stat("pdhg_iters")
+    phase_keys = ("pdhg_iters", "lp_time_s", "sep_time_s", "lp_setup_time_s", "allreduce_calls", "allreduce_bytes")
+    ph0 = {k: model.stat(k) for k in phase_keys}
     t0 = time.perf_counter()
     run_steps(model, args.steps, solves)
     barrier()
     elapsed = time.perf_counter() - t0
-    pdhg_timed = model.stat("pdhg_iters") - p0
+    phases = {k: model.stat(k) - ph0[k] for k in phase_keys}
+    pdhg_timed = phases["pdhg_iters"]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -190,16 +211,23 @@ def main():
                     "algorithmic_bytes_per_launch": avg_b,
                     "timing": "per launch, hipExtLaunchKernelGGL start/stop hipEvents on the engine's own stream "
                               "(the dispatch's begin/end timestamps, as rocprofv3 --kernel-trace reports them)"}
-        roofline = rf("ky", "k_pdhg_y (A x SpMV + dual prox + Halpern update)")
-        # HBM traffic from the PMC counters cannot be collected in-process; the per-launch figure of the
-        # committed rocprofv3 --pmc passes over this same command is reported (profiles/r01_traffic.json)
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        names = {"ky": "k_pdhg_y (A x SpMV + dual prox + Halpern update)",
+                 "kx": "k_pdhg_x (A'y SpMV + primal prox + Halpern update)"}
+        dom = "kx" if d["kx_time_s"] >= d["ky_time_s"] else "ky"          # the kernel with the largest total time in the run
+        oth = "ky" if dom == "kx" else "kx"
+        roofline = rf(dom, names[dom])
+        roofline["total_time_s_in_run"] = d[dom + "_time_s"]
+        # HBM traffic from the PMC counters cannot be collected in-process; the per-launch figure of the committed
+        # rocprofv3 --pmc passes over this same command is reported (profiles/r02_traffic.json, regenerated every round)
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath) and args.workload == "cfg3":
             t = json.load(open(tpath))
-            roofline["traffic"] = t["k_pdhg_y"]["bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; raw sum, see its _note)"
+            key = "k_pdhg_x" if dom == "kx" else "k_pdhg_y"
+            if key in t:
+                roofline["traffic"] = t[key]["bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE, separate passes; see its _note)"
         roofline["other_kernels"] = {
-            "k_pdhg_x": rf("kx", "k_pdhg_x (A'y SpMV + primal prox + Halpern update)"),
+            ("k_pdhg_x" if oth == "kx" else "k_pdhg_y"): rf(oth, names[oth]),
             "k_sep_eval": rf("sweep_eval", "k_sep_eval (separator sweep: g, cut constant, violation)"),
         }
 
@@ -224,17 +252,73 @@ def main():
                           "kernel": "k_sep_eval_blk + k_sep_combine (column-blocked separator sweep)",
                           "workload": "cfg3_hbm: n=%d, m_nl=%d exp/log rows, k=%d" % (hb.n, hb.m_nl, hb.meta["k"]),
                           "launches": int(dn), "avg_launch_us": 1e6 * dt / dn, "algorithmic_bytes_per_launch": db / dn}
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
             t = json.load(open(tpath)).get("k_sep_eval_blk")
             if t:
                 sweep_roofline["traffic"] = t["bytes_per_launch"]
-                sweep_roofline["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction for 16-B/lane streams)"
+                sweep_roofline["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction for 16-B/lane streams)"
         del sm, sep, hb
+
+    # The LP SpMV steps in the HBM regime (tools/spmv_bench.py): cfg4's LP after one un-capped sweep
+    spmv_roofline = None
+    if world == 1 and not args.no_roofline and not args.no_spmv_roofline and args.workload == "cfg3":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import spmv_bench
+        sinst, sm, nviol = spmv_bench.build(1_000_000, device=local_rank)
+        M, nnz = sm.lp_num_rows(), int(sm._lib.ktn_lp_nnz(sm._h))
+        x0, y0 = np.zeros(sm.num_var), np.zeros(M)
+        sm.lp_pdhg_raw(x0, y0, 1e-3, 1.0, 4)
+        keys = [p + q for p in ("kx", "ky") for q in ("_time_s", "_launches", "_bytes")]
+        b0 = {k: sm.stat(k) for k in keys}
+        sm.lp_pdhg_raw(x0, y0, 1e-3, 1.0, 40)
+        dd = {k: sm.stat(k) - b0[k] for k in keys}
+        spmv_roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "workload": "cfg4 LP after one un-capped sweep: n=%d, rows=%d (%d cuts), nnz=%d: CSR + CSC mirror %.0f MB" % (
+                             sinst.n, M, nviol, nnz, 2 * nnz * 12 / 1e6),
+                         "tiled": bool(sm.stat("lp_tiled_builds")), "kernels": {}}
+        for pfx, name in (("kx", "x-step (A'y): k_spmv_tiled + k_x_epilogue"), ("ky", "y-step (A x): k_spmv_tiled + k_y_epilogue")):
+            tt, nl, by = dd[pfx + "_time_s"], max(dd[pfx + "_launches"], 1), dd[pfx + "_bytes"]
+            spmv_roofline["kernels"][name] = {"avg_step_us": 1e6 * tt / nl, "algorithmic_bytes_per_step": by / nl,
+                                              "achieved": by / tt / 1e9, "frac": by / tt / 1e9 / HBM_PEAK_GBS}
+        worst = min(spmv_roofline["kernels"].values(), key=lambda r: r["frac"])
+        spmv_roofline["achieved"], spmv_roofline["frac"] = worst["achieved"], worst["frac"]
+        del sm, sinst
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
+
+    # N > 1: the per-phase split of the timed region, the latency of one all-reduce of an n-vector on this fabric, and the
+    # SAME workload on rank 0's GPU alone (what a strong-scaling ratio has to be taken against)
+    multi = None
+    if world > 1:
+        t = torch.zeros(inst.n + 1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        for _ in range(5):
+            dist.all_reduce(t)
+        barrier()
+        ta = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(t)
+        barrier()
+        ar_us = 1e6 * (time.perf_counter() - ta) / 50
+        multi = {"lp_s": phases["lp_time_s"], "sweep_s": phases["sep_time_s"], "lp_setup_s": phases["lp_setup_time_s"],
+                 "allreduce_calls": phases["allreduce_calls"], "allreduce_MB": phases["allreduce_bytes"] / 1e6,
+                 "allreduce_n_vector_us": ar_us, "exchange": "none (row-sharded LP: every rank keeps its own cuts)"
+                 if not args.replicated_lp else "all-gather of cut blocks", "lp_rows_rank0": model.lp_num_rows()}
+        if rank == 0:
+            one = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, device=local_rank))
+            one.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense,
+                            ktn.SeparableNLP(inst))
+            run_steps(one, args.warmup)
+            torch.cuda.synchronize()
+            t1g = time.perf_counter()
+            run_steps(one, args.steps)
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1g
+            multi["same_workload_one_gpu"] = {"value": args.steps / e1, "ms_per_step": 1e3 * e1 / args.steps}
+            del one
+        barrier()
 
     if rank == 0:
         out = {
@@ -246,11 +330,15 @@ def main():
                                    "planted non-degenerate vertex optimum, f_tol=1e-6" % (
                                        args.workload, inst.n, inst.m_lin, inst.m_nl, inst.meta["family"], inst.meta["k"],
                                        args.seed),
-                       "parallelism": "1 GPU" if world == 1 else "nl-rows sharded x%d, replicated LP, all-gather of cuts" % world},
+                       "parallelism": "1 GPU" if world == 1 else (
+                           "nl-rows sharded x%d, replicated LP, all-gather of cuts" % world if args.replicated_lp else
+                           "rows sharded x%d (linear rows and NL rows by blocks, cuts stay on their rank), x replicated, "
+                           "one RCCL all-reduce of an n-vector per PDHG iteration" % world)},
             "wall_to_ftol_s": wall_to_ftol, "ecp_iters_to_ftol": iters_to_ftol, "status": status, "objective": obj,
             "planted_objective": inst.opt_obj, "objective_relerr": abs(obj - inst.opt_obj) / max(1.0, abs(inst.opt_obj)),
             "pdhg_iters_per_step": pdhg_timed / args.steps, "solves_in_timed_region": len(solves),
-            "roofline": roofline, "sweep_roofline": sweep_roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "sweep_roofline": sweep_roofline, "spmv_roofline": spmv_roofline, "cpu_baseline": cpu,
+            "multi_gpu": multi,
         }
         print(json.dumps(out))
     if dist is not None:

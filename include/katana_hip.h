@@ -310,6 +310,24 @@ int ktn_lp_purge(ktn_handle h, int64_t* rows_removed);
 int ktn_lp_append_rows(ktn_handle h, int64_t nrows, const int64_t* rowptr, const int32_t* col,
                        const double* val, const double* lo, const double* hi);
 
+/* ---- row-sharded LP over several GPUs (no reference counterpart: it splits the LP re-solve of
+ * src/model.jl:259 and the cut loop of :272-283 over the ranks) -------------------------------------------------------
+ * One process per GPU.  Every rank creates a handle, joins the group with ONE of the two calls below BEFORE
+ * ktn_loadproblem, and loads ITS shard: all variables and the objective, a block of the linear rows and a block of the NL
+ * rows (katana.jl_amd/distributed.py::shard_rows).  ktn_optimize is then a collective call: x is replicated, every rank
+ * keeps the cuts it generates (no cut exchange), A x is local and A'y is a local partial plus an all-reduce of an n-vector
+ * per PDHG iteration; the stop rule and every restart decision use all-reduced quantities, so all ranks return the same
+ * status, objective and solution.  With a nonlinear objective the epigraph row belongs to rank 0.
+ *   ktn_dist_unique_id  : 128-byte RCCL id, made by ONE rank and sent to the others (e.g. torch.distributed.broadcast)
+ *   ktn_dist_init_rccl  : collectives = ncclAllReduce on the engine's stream (RCCL over xGMI)
+ *   ktn_dist_init_callback : collectives through the caller: cb(user, host_buf, count, op) must all-reduce host_buf in
+ *                         place over the ranks (op 0: sum, 1: max) and return 0 -- the engine stages through the host.
+ *                         For tests (gloo; several ranks sharing one GPU, which RCCL does not allow).                  */
+typedef int (*ktn_allreduce_cb)(void* user, double* host_buf, int64_t count, int32_t op);
+int ktn_dist_unique_id(char* out128);
+int ktn_dist_init_rccl(ktn_handle h, const char* uid128, int32_t rank, int32_t world);
+int ktn_dist_init_callback(ktn_handle h, int32_t rank, int32_t world, ktn_allreduce_cb cb, void* user);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,8 @@ EVAL_ROWS_CB = C.CFUNCTYPE(c_i32, C.c_void_p, P(c_f64), P(c_f64), P(c_f64))
 EVAL_OBJ_CB = C.CFUNCTYPE(c_i32, C.c_void_p, P(c_f64), P(c_f64), P(c_f64))
 
 
+ALLREDUCE_CB = C.CFUNCTYPE(c_i32, C.c_void_p, P(c_f64), c_i64, c_i32)
+
 # name -> (restype, argtypes); every function declared in include/katana_hip.h
 PROTOTYPES = {
     "ktn_abi_version": (c_i32, []),
@@ -94,6 +96,9 @@ PROTOTYPES = {
     "ktn_lp_enable_global_lists": (c_i32, [C.c_void_p, c_i64]),
     "ktn_last_sweep_slots": (c_i32, [C.c_void_p, P(c_i64), c_i64, P(c_i64)]),
     "ktn_lp_append_rows_nl": (c_i32, [C.c_void_p, c_i64, P(c_i64), P(c_i32), P(c_f64), P(c_f64), P(c_f64), P(c_i64)]),
+    "ktn_dist_unique_id": (c_i32, [C.c_char_p]),
+    "ktn_dist_init_rccl": (c_i32, [C.c_void_p, C.c_char_p, c_i32, c_i32]),
+    "ktn_dist_init_callback": (c_i32, [C.c_void_p, c_i32, c_i32, C.c_void_p, C.c_void_p]),
     "ktn_lp_append_rows": (c_i32, [C.c_void_p, c_i64, P(c_i64), P(c_i32), P(c_f64), P(c_f64), P(c_f64)]),
 }
 

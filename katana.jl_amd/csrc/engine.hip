@@ -22,6 +22,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 #include "dense_lp.hpp"
@@ -317,12 +319,57 @@ struct Engine {
         d_anynf.resize(2, stream);
     }
     ~Engine() {
+        if (dist.comm) (void)ncclCommDestroy(dist.comm);
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
     void sync() { KTN_HIP(hipStreamSynchronize(stream)); }
     void check_launch() { KTN_HIP(hipGetLastError()); }
+
+    // ------------------------------------------------------- row-sharded LP over several GPUs ---
+    // (kernels.hpp "row-sharded".)  world > 1: this handle holds a block of the linear rows and the
+    // cuts of its block of NL rows; x is replicated, y local.  Collectives run on the engine's own stream: RCCL (xGMI)
+    // when the communicator was made by ktn_dist_init_rccl, or a host callback (tests: gloo, ranks sharing one GPU).
+    struct DistCtx {
+        int rank = 0, world = 1;
+        ncclComm_t comm = nullptr;
+        ktn_allreduce_cb cb = nullptr;
+        void* user = nullptr;
+        std::vector<double> hbuf;
+    } dist;
+    DBuf<double> d_red;            // small device scratch for scalar reductions
+    bool row_sharded() const { return dist.world > 1; }
+    void allreduce(double* d, size_t n, int op) {          // in place; op 0: sum, 1: max
+        if (dist.world <= 1 || n == 0) return;
+        stats["allreduce_calls"] += 1.0;
+        stats["allreduce_bytes"] += 8.0 * (double)n;
+        if (dist.comm) {
+            size_t ea = 0, eb = 0;
+            if (prm.profile) { ea = ev_get(); eb = ev_get(); KTN_HIP(hipEventRecord(ev_pool[ea], stream)); }
+            const ncclResult_t r = ncclAllReduce(d, d, n, ncclDouble, op ? ncclMax : ncclSum, dist.comm, stream);
+            if (r != ncclSuccess) throw Error(KTN_E_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+            if (prm.profile) { KTN_HIP(hipEventRecord(ev_pool[eb], stream)); ev_recs.push_back({3, ea, eb, 8.0 * (double)n}); }
+        } else {
+            KTN_REQUIRE(dist.cb != nullptr, "row-sharded handle without a collective transport");
+            dist.hbuf.resize(n);
+            KTN_HIP(hipMemcpyAsync(dist.hbuf.data(), d, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+            sync();
+            if (dist.cb(dist.user, dist.hbuf.data(), (int64_t)n, op) != 0) throw Error(KTN_E_CALLBACK, "all-reduce callback failed");
+            KTN_HIP(hipMemcpyAsync(d, dist.hbuf.data(), n * sizeof(double), hipMemcpyHostToDevice, stream));
+            sync();
+        }
+    }
+    // k values reduced over the ranks (host in, host out); every rank gets the identical result
+    void allreduce_host(double* v, int k, int op) {
+        if (dist.world <= 1) return;
+        d_red.resize(64, stream);
+        KTN_REQUIRE(k <= 64, "allreduce_host: too many values");
+        KTN_HIP(hipMemcpyAsync(d_red.p, v, (size_t)k * sizeof(double), hipMemcpyHostToDevice, stream));
+        allreduce(d_red.p, (size_t)k, op);
+        KTN_HIP(hipMemcpyAsync(v, d_red.p, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, stream));
+        sync();
+    }
 
     // ------------------------------------------------------------------ profiling ---
     size_t ev_get() {
@@ -336,7 +383,7 @@ struct Engine {
     // profile mode: the timed launches go through hipExtLaunchKernelGGL, whose start/stop events
     // carry the dispatch's own begin/end timestamps (what rocprofv3 --kernel-trace reports)
     void ev_flush() {   // stream must be synchronised
-        static const char* names[3] = {"kx", "ky", "sweep_eval"};
+        static const char* names[4] = {"kx", "ky", "sweep_eval", "allreduce"};
         for (auto& r : ev_recs) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ev_pool[r.a], ev_pool[r.b]) == hipSuccess) {
@@ -479,7 +526,8 @@ struct Engine {
         // violated only the cut_cap_factor * n_lp deepest get a cut this iteration (the reference cuts every violated
         // row; with 1e6 NL rows over 1e5 variables that makes the LP 10x larger than it needs to be).  Ties at the
         // threshold are all kept.  Never triggers on the reference's own test models.
-        const int64_t cap = (prm.cut_cap_factor > 0.0) ? std::max<int64_t>((int64_t)(prm.cut_cap_factor * (double)n_lp), prm.cut_cap_min) : 0;
+        int64_t cap = (prm.cut_cap_factor > 0.0) ? std::max<int64_t>((int64_t)(prm.cut_cap_factor * (double)n_lp), prm.cut_cap_min) : 0;
+        if (cap > 0 && row_sharded()) cap = std::max<int64_t>(cap / dist.world, 1);      // every rank selects among ITS rows
         if (cap > 0 && V > cap && !anynf) {
             d_dkeys.resize((size_t)m_nl, stream); d_dsorted.resize((size_t)m_nl, stream);
             LAUNCH_1(k_depth_keys, m_nl, stream, P, d_nlrows.p, m_nl, d_g.p, d_flag.p, d_dkeys.p);
@@ -530,6 +578,18 @@ struct Engine {
         }
         sync();
         stats["sep_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    // sweep + (row-sharded) the stop rule's quantities over all ranks: number of violated rows, largest violation, error flag
+    void global_sweep(const double* d_x, double f_tol, int64_t* nviol, double* maxviol, bool* nonfinite) {
+        sweep(d_x, f_tol, nviol, maxviol, nonfinite);
+        if (!row_sharded()) return;
+        double v[2] = {(double)*nviol, *nonfinite ? 1.0 : 0.0};
+        allreduce_host(v, 2, 0);
+        double mv = *maxviol;
+        allreduce_host(&mv, 1, 1);
+        *nviol = (int64_t)(v[0] + 0.5);
+        *nonfinite = v[1] > 0.0;
+        *maxviol = mv;
     }
     double sweep_bytes = 0.0;
 
@@ -771,7 +831,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
         uv.push_back(kInf);
         h_lb[m0] = (sense == KTN_MAX) ? 0.0 : -kInf;    // model.jl:144
         h_ub[m0] = (sense == KTN_MAX) ? kInf : 0.0;
-        h_nlrows.push_back((int32_t)m0);
+        if (dist.rank == 0) h_nlrows.push_back((int32_t)m0);      // row-sharded: the epigraph row belongs to rank 0
     }
     m_nl = (int64_t)h_nlrows.size();
     has_inf_bound = false;
@@ -941,7 +1001,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
             else vtx[j] = 0.0;
         }
         if (!ok) std::fprintf(stderr, "WARNING: Problem variables insufficiently bounded!\n");      // model.jl:156-157
-        if (ok) {
+        if (ok && dist.rank == 0) {
             KTN_HIP(hipMemcpyAsync(d_xs.p, vtx.data(), (n0 + 1) * sizeof(double), hipMemcpyHostToDevice, stream));
             precompute_all(d_xs.p);
             std::vector<double> g1 = d_g.to_host(stream);
@@ -1139,7 +1199,7 @@ void Engine::compute_scaling(bool identity) {
     }
     const int gr = pick_group((double)NNZ / (double)std::max<int64_t>(M, 1));
     const int gc = pick_group((double)NNZ / (double)std::max<int64_t>(n_lp, 1));
-    if (!identity && M > 0) {
+    if (!identity && (M > 0 || row_sharded())) {
         const int passes = warm ? prm.lp_ruiz_warm : prm.lp_ruiz_iters;
         for (int it = 0; it <= passes; ++it) {
             const int mode = (it == passes) ? 1 : 0;   // last pass: Pock-Chambolle (alpha = 1)
@@ -1149,6 +1209,10 @@ void Engine::compute_scaling(bool identity) {
             }
             LAUNCH_G(gr, k_scale_stat, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, mode, statr.p);
             LAUNCH_G(gc, k_scale_stat, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, statc.p);
+            if (row_sharded()) {                       // a column's max / sum runs over the rows of every rank
+                if (M == 0) LAUNCH_1(k_fill, n_lp, stream, n_lp, statc.p, 0.0);
+                allreduce(statc.p, (size_t)n_lp, mode ? 0 : 1);
+            }
             LAUNCH_1(k_scale_apply2, std::max(M, n_lp), stream, M, dr.p, statr.p, n_lp, dc.p, statc.p);
         }
     }
@@ -1251,6 +1315,16 @@ void Engine::launch_y(const SpMat& A, double sigma, double w, double rho, hipEve
 }
 void Engine::launch_x(const SpMat& AT, double tau, double w, double rho, bool update, hipEvent_t e0, hipEvent_t e1) {
     const int64_t n = n_lp;
+    if (row_sharded()) {
+        // local partial of A'y, summed over the ranks, then the element-wise primal step on the replicated x
+        if (M == 0) LAUNCH_1(k_fill, n, stream, n, pv.p, 0.0);
+        if (e0) LAUNCH_G_EV(grp_cols, k_spmv, n, stream, e0, e1, n, AT, yh.p, pv.p);
+        else LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, yh.p, pv.p);
+        allreduce(pv.p, (size_t)n, 0);
+        if (update) LAUNCH_1(k_x_prox<true>, n, stream, n, pv.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        else LAUNCH_1(k_x_prox<false>, n, stream, n, pv.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        return;
+    }
     if (update) {
         if (tiled_on && M > 0) {
             launch_tiled(tAT, n, M, yh.p, e0);
@@ -1281,10 +1355,22 @@ void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double si
             hipLaunchKernelGGL((k_pdhg_y_long<true>), dim3((unsigned)n_long), dim3(kLongBlock), 0, stream, d_longrows.p, A, xth.p, xh.p,
                                yh.p, y0h.p, yth.p, loh.p, hih.p, dr.p, sigma, 0.0, 1.0, prow + (size_t)brow * kChkQ);
     }
-    LAUNCH_G(grp_cols, k_chk_cols, n, stream, n, AT, xh.p, xth.p, x0h.p, yth.p, ch.p, lh.p, uh.p, dc.p, pcol);
     chk_nrow = (m > 0) ? (int)(brow + n_long) : 0;
-    chk_ncol = (int)bcol;
+    if (row_sharded()) {
+        if (m == 0) LAUNCH_1(k_fill, n, stream, n, pv.p, 0.0);
+        LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, yth.p, pv.p);
+        allreduce(pv.p, (size_t)n, 0);
+        chk_ncol = ceil_div(n, kBlock);             // <= bcol: the column partials fit the same region
+        LAUNCH_1(k_chk_cols_vec, n, stream, n, pv.p, xh.p, xth.p, x0h.p, ch.p, lh.p, uh.p, dc.p, pcol);
+    } else {
+        LAUNCH_G(grp_cols, k_chk_cols, n, stream, n, AT, xh.p, xth.p, x0h.p, yth.p, ch.p, lh.p, uh.p, dc.p, pcol);
+        chk_ncol = (int)bcol;
+    }
     hipLaunchKernelGGL(k_chk_final, dim3(2), dim3(kRedBlocks), 0, stream, prow, chk_nrow, pcol, chk_ncol, chkout.p);   // rows | columns
+    if (row_sharded()) {                            // row sums: every rank's rows; column sums are identical already
+        allreduce(chkout.p, 12, 0);
+        allreduce(chkout.p + 12, 4, 1);
+    }
 }
 
 // LP dispatch.  The first-order method is the default: on the large sparse LPs of the hot path it is the only
@@ -1294,7 +1380,7 @@ void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double si
 // columns, the exact kernel finishes the solve; each stall doubles the number of following solves that go to
 // the exact kernel directly.
 LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling) {
-    const bool dense_ok = mode == 0 && !identity_scaling && prm.lp_dense_after != 0 && n_lp >= 1 && n_lp <= kDenseMaxN &&
+    const bool dense_ok = mode == 0 && !identity_scaling && !row_sharded() && prm.lp_dense_after != 0 && n_lp >= 1 && n_lp <= kDenseMaxN &&
                           M * n_lp <= 8000000;
     if (!dense_ok) return lp_solve_core(tol_p, tol_g, mode, identity_scaling);
     if (prm.lp_dense_after < 0 || dense_credit > 0) {
@@ -1406,8 +1492,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     // power iteration keep the CSR / CSC kernels
     {
         static const char* tenv = std::getenv("KTN_TILED");
-        tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn;
-        if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0;
+        tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn && !row_sharded();
+        if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0 && !row_sharded();
         if (tiled_on) {
             auto tt = std::chrono::steady_clock::now();
             tiled_on = build_tiled(tA, M, n_lp, lp_rowptr.p, lp_col.p, r_sval.p, kLongRow) &&
@@ -1427,7 +1513,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     // last ||A^||_2 <= 1 is guaranteed (Pock & Chambolle 2011, Lemma 2): eta_safe = 0.998; always using
     // it costs 40 % (cfg3) to 170 % (cfg2) more PDHG iterations than the estimate.
     double smax = 0.0;
-    if (m > 0 && NNZ > 0) {
+    if ((m > 0 && NNZ > 0) || row_sharded()) {
         // 20 passes from a hashed start vector.  Norms stay on the device (k_normalize reads them): one host
         // round trip at the end instead of one per pass.  (Measured: warm-starting v from the previous LP makes
         // the estimate tighter and the step therefore smaller -- cfg3 then needs 14 700 instead of 7 800 PDHG
@@ -1452,10 +1538,12 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             const bool norm_now = (it % 4 == 3) || it >= iters - 2;
             if (norm_now) {
                 LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, pw.p, xbar.p);
+                allreduce(xbar.p, (size_t)n, 0);            // row-sharded: A'A v = sum over the ranks of A_r'(A_r v)
                 dot_dev(xbar.p, nrm);                       // on the last pass: ||A'A v||^2 with ||v|| = 1
                 LAUNCH_1(k_normalize, n, stream, n, xbar.p, nrm, pv.p);
             } else {
                 LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, pw.p, pv.p);
+                allreduce(pv.p, (size_t)n, 0);
             }
         }
         double nv2 = 0.0;
@@ -1464,7 +1552,9 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         smax = (nv2 > 0.0) ? std::sqrt(std::sqrt(nv2)) : 0.0;     // sigma_max^2 ~ ||A'A v||
     }
     lap("lp_power_time_s", tp);
-    const double fro = (NNZ > 0) ? std::sqrt(dev_dot(NNZ, r_sval.p, r_sval.p)) : 0.0;   // ||A||_2 <= ||A||_F
+    double fro2 = (NNZ > 0) ? dev_dot(NNZ, r_sval.p, r_sval.p) : 0.0;                  // ||A||_2 <= ||A||_F
+    allreduce_host(&fro2, 1, 0);
+    const double fro = std::sqrt(fro2);
     if (!(smax > 0.0)) smax = fro;
     const double eta_safe = 0.998 / std::max(identity_scaling ? fro : std::min(1.0, fro), 1e-12);
     double eta = std::max(0.998 / std::max(smax, 1e-12), eta_safe);
@@ -1474,7 +1564,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     sync();
     stats["lp_setup_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double nc2 = dev_dot(n, ch.p, ch.p);
-    const double nb2 = (m > 0) ? dev_finite_sq(m, loh.p) + dev_finite_sq(m, hih.p) : 0.0;
+    double nb2 = (m > 0) ? dev_finite_sq(m, loh.p) + dev_finite_sq(m, hih.p) : 0.0;
+    allreduce_host(&nb2, 1, 0);
     const double omega_ref = (nc2 > 0.0 && nb2 > 0.0) ? std::sqrt(nc2 / nb2) : 1.0;
     double om = (have_omega && mode == 0) ? omega : omega_ref;
     const double rho = 1.0;
@@ -1691,8 +1782,8 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
     // power iteration keep the CSR / CSC kernels
     {
         static const char* tenv = std::getenv("KTN_TILED");
-        tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn;
-        if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0;
+        tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn && !row_sharded();
+        if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0 && !row_sharded();
         if (tiled_on) {
             auto tt = std::chrono::steady_clock::now();
             tiled_on = build_tiled(tA, M, n_lp, lp_rowptr.p, lp_col.p, r_sval.p, kLongRow) &&
@@ -1741,6 +1832,7 @@ bool Engine::recession_ray() {
         double w = 0.0;
         KTN_HIP(hipMemcpyAsync(&w, d_scal.p + 1, 8, hipMemcpyDeviceToHost, stream));
         sync();
+        allreduce_host(&w, 1, 1);
         LAUNCH_1(k_fill, 1, stream, (int64_t)1, box.p + n0, 1.0 + w);
     }
     LpResult R = lp_solve(1e-9, 1e-7, 1);
@@ -1755,7 +1847,7 @@ void Engine::boundroutine() {
         int64_t nviol = 0;
         double mv = 0.0;
         bool nonfin = false;
-        sweep(d_xs.p, prm.f_tol, &nviol, &mv, &nonfin);
+        global_sweep(d_xs.p, prm.f_tol, &nviol, &mv, &nonfin);
         if (nonfin) { status = KTN_STATUS_ERROR; return; }
         if (nviol > 0) break;   // !allsat -> stop searching in this direction
     }
@@ -1811,7 +1903,7 @@ void Engine::step(int32_t* done) {
     int64_t nviol = 0;
     double mv = 0.0;
     bool nonfin = false;
-    sweep(lp_x.p, prm.f_tol, &nviol, &mv, &nonfin);                      // model.jl:268-283
+    global_sweep(lp_x.p, prm.f_tol, &nviol, &mv, &nonfin);               // model.jl:268-283
     if (nonfin) { status = KTN_STATUS_ERROR; return; }
     last_maxviol = mv;
     const bool sat_now = (nviol == 0);
@@ -1842,7 +1934,7 @@ void Engine::step(int32_t* done) {
     *done = (allsat || iter >= prm.iter_cap) ? 1 : 0;
     // Terminal refinement of small problems: the reference's simplex vertices end Kelley's method with the last
     // violation far below f_tol (its tests ask the objective to 1e-6 / 1e-7); a first-order LP ends AT f_tol.
-    if (allsat && !eps_stop && !polish_done && !sharded_rows && prm.polish_factor > 0.0 && prm.polish_factor < 1.0 &&
+    if (allsat && !eps_stop && !polish_done && !sharded_rows && !row_sharded() && prm.polish_factor > 0.0 && prm.polish_factor < 1.0 &&
         prm.polish_max_iter > 0 && n_lp <= prm.polish_max_var && m_nl > 0) {
         polishing = true;
         polish_count = 0;
@@ -2286,6 +2378,41 @@ int ktn_lp_purge(ktn_handle h, int64_t* rows_removed) {
         return KTN_OK;
     })
 }
+// ---- row-sharded LP over several GPUs
+int ktn_dist_unique_id(char* out128) {
+    if (!out128) return KTN_E_INVALID;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return KTN_E_HIP;
+    static_assert(sizeof(id.internal) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(out128, id.internal, 128);
+    return KTN_OK;
+}
+int ktn_dist_init_rccl(ktn_handle h, const char* uid128, int32_t rank, int32_t world) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(!e->loaded, "ktn_dist_init_*: call before loadproblem");
+        KTN_REQUIRE(uid128 && world >= 1 && rank >= 0 && rank < world, "ktn_dist_init_rccl: bad rank / world");
+        e->dist.rank = rank; e->dist.world = world;
+        if (world > 1) {
+            ncclUniqueId id;
+            std::memcpy(id.internal, uid128, 128);
+            KTN_HIP(hipSetDevice(e->device));
+            const ncclResult_t r = ncclCommInitRank(&e->dist.comm, world, id, rank);
+            if (r != ncclSuccess) throw ktn::Error(KTN_E_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+        }
+        return KTN_OK;
+    })
+}
+int ktn_dist_init_callback(ktn_handle h, int32_t rank, int32_t world, ktn_allreduce_cb cb, void* user) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(!e->loaded, "ktn_dist_init_*: call before loadproblem");
+        KTN_REQUIRE(world >= 1 && rank >= 0 && rank < world && (world == 1 || cb), "ktn_dist_init_callback: bad arguments");
+        e->dist.rank = rank; e->dist.world = world; e->dist.cb = cb; e->dist.user = user;
+        return KTN_OK;
+    })
+}
+
 int ktn_lp_append_rows(ktn_handle h, int64_t nrows, const int64_t* rowptr, const int32_t* col, const double* val,
                        const double* lo, const double* hi) {
     return ktn_lp_append_rows_nl(h, nrows, rowptr, col, val, lo, hi, nullptr);

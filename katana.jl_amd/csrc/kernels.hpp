@@ -896,6 +896,50 @@ __global__ __launch_bounds__(kBlock) void k_chk_cols(int64_t n, SpMat AT, const 
     chk_block_store<kBlock>(a, partials);
 }
 
+// ================================================== LP: row-sharded over several GPUs ===============================
+//   Every rank holds a block of the linear rows and the cuts of ITS block of NL rows; x is
+// replicated, y is local.  A x is local; A'y is the local partial k_spmv(A'_r, y_r) summed over the ranks by ONE
+// all-reduce of an n-vector per PDHG iteration, after which every rank runs the same element-wise primal step:
+template <bool UPDATE>
+__global__ __launch_bounds__(kBlock) void k_x_prox(int64_t n, const double* __restrict__ aty, double* __restrict__ x,
+                                                   const double* __restrict__ x0, double* __restrict__ xt, double* __restrict__ xbar,
+                                                   const double* __restrict__ c, const double* __restrict__ l,
+                                                   const double* __restrict__ u, double tau, double w, double rho) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    const double xv = x[j];
+    const double xtv = clampd(xv - tau * (c[j] - aty[j]), l[j], u[j]);
+    if (UPDATE) { xbar[j] = 2.0 * xtv - xv; x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0[j]; }
+    else xt[j] = xtv;
+}
+// column side of the check from the all-reduced A'yt (same sums as k_chk_cols; identical on every rank)
+__global__ __launch_bounds__(kBlock) void k_chk_cols_vec(int64_t n, const double* __restrict__ atyv, const double* __restrict__ x,
+                                                         const double* __restrict__ xt, const double* __restrict__ x0,
+                                                         const double* __restrict__ c, const double* __restrict__ l,
+                                                         const double* __restrict__ u, const double* __restrict__ dc,
+                                                         double* __restrict__ partials) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    ChkAcc a; a.init();
+    if (j < n) {
+        const double xtv = xt[j], xv = x[j], x0v = x0[j], cj = c[j], lj = l[j], uj = u[j], dcj = dc[j], aty = atyv[j];
+        const double dx = xtv - xv;
+        a.s[5] += dx * dx;
+        a.s[6] += cj * xtv;
+        const double r = cj - aty;
+        double bad = 0.0;
+        if (r > 0.0) { if (isfinite(lj)) a.s[7] += lj * r; else bad = r; }
+        else if (r < 0.0) { if (isfinite(uj)) a.s[7] += uj * r; else bad = -r; }
+        const double d0 = xtv - x0v;
+        a.s[8] += d0 * d0;
+        a.s[9] += xtv * xtv;
+        a.s[13] = fmax(a.s[13], bad / dcj);
+        const double r0 = -aty;
+        if (r0 > 0.0) { if (isfinite(lj)) { a.s[10] += lj * r0; a.s[11] += fabs(lj * r0); } else a.s[14] = fmax(a.s[14], r0); }
+        else if (r0 < 0.0) { if (isfinite(uj)) { a.s[10] += uj * r0; a.s[11] += fabs(uj * r0); } else a.s[14] = fmax(a.s[14], -r0); }
+    }
+    chk_block_store<kBlock>(a, partials);
+}
+
 // ================================================== LP: tiled SpMV for LPs beyond the caches =========================
 // (DESIGN.md section 4 "HBM-regime SpMV".)  In CSR form every 8-byte gather of the input vector is its own L1 miss and
 // drags a 128-byte line from L2; with tens of millions of entries that traffic, not the 12 B/entry matrix stream, is

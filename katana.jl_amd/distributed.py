@@ -212,3 +212,91 @@ class ShardedKatanaModel:
     def numiters(self): return self.iter
     def numcuts(self): return self.m.numcuts()
     def stat(self, name): return self.m.stat(name)
+
+
+# =====================================================================================================================
+# Row-sharded LP: every rank keeps the cuts it generates, x is replicated, A'y is a local
+# partial plus ONE all-reduce of an n-vector per PDHG iteration -- inside the engine, on its own stream (include/
+# katana_hip.h "row-sharded LP").  No cut exchange, no host loop: ktn_optimize itself is the collective call.
+# =====================================================================================================================
+def shard_rows(inst, rank, world):
+    """rank's shard for the row-sharded LP: all variables and the objective, the block [m_lin r / w, m_lin (r+1) / w) of the
+    linear rows and the block of the NL rows given by shard_bounds"""
+    ml = inst.m_lin
+    l0, l1 = (ml * rank) // world, (ml * (rank + 1)) // world
+    n0, n1 = shard_bounds(inst.m_nl, rank, world)
+    rp = np.asarray(inst.rowptr)
+    rows = np.concatenate([np.arange(l0, l1), np.arange(ml + n0, ml + n1)])
+    keep = np.concatenate([np.arange(rp[l0], rp[l1]), np.arange(rp[ml + n0], rp[ml + n1])])
+    lens = np.diff(rp)[rows]
+    new_rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    return SeparableInstance(
+        n=inst.n, l_var=inst.l_var, u_var=inst.u_var, sense=inst.sense, rowptr=new_rp,
+        col=np.asarray(inst.col)[keep], kind=np.asarray(inst.kind)[keep], p0=np.asarray(inst.p0)[keep],
+        p1=np.asarray(inst.p1)[keep], rconst=np.asarray(inst.rconst)[rows], l_constr=np.asarray(inst.l_constr)[rows],
+        u_constr=np.asarray(inst.u_constr)[rows], obj_col=inst.obj_col, obj_kind=inst.obj_kind, obj_p0=inst.obj_p0,
+        obj_p1=inst.obj_p1, obj_const=inst.obj_const, xhat=inst.xhat, opt_obj=inst.opt_obj, m_lin=l1 - l0, m_nl=n1 - n0,
+        meta=dict(inst.meta, row_shard=(rank, world)))
+
+
+def make_allreduce_callback(dist):
+    """ktn_allreduce_cb over torch.distributed (any backend that reduces CPU tensors, i.e. gloo): the engine hands over a host
+    buffer, the reduction happens in place."""
+    import ctypes as C
+    import torch
+    from . import _lib as L
+
+    def cb(_user, buf, count, op):
+        try:
+            t = torch.from_numpy(np.ctypeslib.as_array(buf, (int(count),)))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
+            return 0
+        except Exception:                       # never unwind through the C ABI
+            return 1
+    return L.ALLREDUCE_CB(cb)
+
+
+class RowShardedKatanaModel:
+    """KatanaNonlinearModel over `world` GPUs with the LP itself sharded by rows.  Same getters and stepping interface as the
+    single-GPU model; optimize / ecp_step / lp_solve are collective calls (every rank must make them)."""
+
+    def __init__(self, solver, inst, rank, world, dist=None, transport="auto"):
+        import ctypes as C
+        from . import _lib as L
+        self.rank, self.world, self.dist = rank, world, dist
+        self.inst = shard_rows(inst, rank, world) if world > 1 else inst
+        self.m = NonlinearModel(solver)
+        lib, h = self.m._lib, self.m._h
+        self._cb = None
+        if world > 1:
+            if transport == "auto":
+                transport = "rccl" if dist.get_backend() == "nccl" else "callback"
+            if transport == "rccl":
+                import torch
+                uid = C.create_string_buffer(128)
+                if rank == 0:
+                    L.check(h, lib.ktn_dist_unique_id(uid))
+                dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+                t = torch.tensor(list(uid.raw), dtype=torch.uint8, device=dev)
+                dist.broadcast(t, src=0)
+                raw = bytes(t.cpu().tolist())
+                L.check(h, lib.ktn_dist_init_rccl(h, raw, rank, world))
+            else:
+                self._cb = make_allreduce_callback(dist)
+                L.check(h, lib.ktn_dist_init_callback(h, rank, world, C.cast(self._cb, C.c_void_p), None))
+        self.transport = transport if world > 1 else "none"
+        s = self.inst
+        self.m.loadproblem(s.n, s.num_constr, s.l_var, s.u_var, s.l_constr, s.u_constr, s.sense, SeparableNLP(s))
+
+    def __getattr__(self, name):                # getters, stepping interface, stats: those of the local handle
+        return getattr(self.m, name)
+
+    def numcuts_global(self):
+        """cuts generated on all ranks (numcuts() is this rank's count; the linear rows are counted once, src/model.jl:77)"""
+        import torch
+        t = torch.tensor([float(self.m.numcuts())], dtype=torch.float64)
+        if self.world > 1:
+            if self.dist.get_backend() == "nccl":
+                t = t.cuda()
+            self.dist.all_reduce(t)
+        return int(t.item())

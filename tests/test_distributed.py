@@ -198,3 +198,153 @@ def test_sharded_world1_with_purging_equals_engine_loop():
     b = hip_load_instance(ktn, inst, **kw)
     assert b.optimize() == "Optimal"
     assert a.getobjval() == b.getobjval() and a.numiters() == b.numiters() and a.numcuts() == b.numcuts()
+
+
+# =====================================================================================================================
+# Row-sharded LP (include/katana_hip.h "row-sharded LP")
+# =====================================================================================================================
+def test_row_shards_partition_linear_and_nl_rows():
+    import katana_jl_amd as ktn
+    from katana_jl_amd.distributed import shard_rows
+    inst = ktn.instances.make_instance(n=300, m_nl=37, k=8, family="quad", seed=1)
+    for world in (1, 2, 3, 8):
+        seen_rows, nnz = [], 0
+        for r in range(world):
+            s = shard_rows(inst, r, world)
+            assert s.n == inst.n and np.array_equal(s.obj_p0, inst.obj_p0)          # variables and objective replicated
+            assert s.num_constr == s.m_lin + s.m_nl and s.rowptr[-1] == len(s.col)
+            # every shard row is a row of the instance, bit for bit
+            l0 = (inst.m_lin * r) // world
+            n0 = (inst.m_nl * r) // world
+            for k in range(s.num_constr):
+                g = l0 + k if k < s.m_lin else inst.m_lin + n0 + (k - s.m_lin)
+                seen_rows.append(g)
+                a, b = inst.rowptr[g], inst.rowptr[g + 1]
+                assert np.array_equal(s.col[s.rowptr[k]:s.rowptr[k + 1]], inst.col[a:b])
+                assert np.array_equal(s.p0[s.rowptr[k]:s.rowptr[k + 1]], inst.p0[a:b])
+                assert s.u_constr[k] == inst.u_constr[g] and s.rconst[k] == inst.rconst[g]
+            nnz += len(s.col)
+        assert sorted(seen_rows) == list(range(inst.num_constr)) and nnz == len(inst.col)   # a partition
+
+
+def _pdhg_reflected_halpern(A_local, c, l, u, lo, hi, iters, tau, sigma, allreduce):
+    """the engine's iteration (csrc/kernels.hpp k_x_prox / k_pdhg_y) in numpy; `allreduce` sums an n-vector over the ranks"""
+    n, m = len(c), A_local.shape[0]
+    x, y = np.zeros(n), np.zeros(m)
+    x0, y0 = x.copy(), y.copy()
+    for k in range(iters):
+        w = (k + 1.0) / (k + 2.0)
+        aty = allreduce(A_local.T @ y)                               # local partial -> sum over ranks
+        xt = np.clip(x - tau * (c - aty), l, u)
+        xbar = 2 * xt - x
+        x = w * (2 * xt - x) + (1 - w) * x0
+        v = y - sigma * (A_local @ xbar)
+        yt = v + sigma * np.clip(-v / sigma, lo, hi)
+        y = w * (2 * yt - y) + (1 - w) * y0
+    return x, y
+
+
+def _lin_block(s):
+    import scipy.sparse as sp
+    rp = s.rowptr[:s.m_lin + 1]
+    A = sp.csr_matrix((s.p0[:rp[-1]], s.col[:rp[-1]], rp), shape=(s.m_lin, s.n))
+    return A, s.l_constr[:s.m_lin], s.u_constr[:s.m_lin]
+
+
+def _worker_rowshard_logic(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import katana_jl_amd as ktn
+    from katana_jl_amd.distributed import make_allreduce_callback, shard_rows
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    inst = ktn.instances.make_instance(n=300, m_nl=20, k=8, family="explog", seed=4)
+    s = shard_rows(inst, rank, world)
+    A, lo, hi = _lin_block(s)
+    c = np.zeros(inst.n); c[inst.obj_col] = inst.obj_p0
+
+    def allreduce(v):
+        t = torch.from_numpy(np.ascontiguousarray(v)); dist.all_reduce(t); return t.numpy()
+    x, y = _pdhg_reflected_halpern(A, c, inst.l_var, inst.u_var, lo, hi, 60, 0.05, 0.05, allreduce)
+    # the transport the engine uses with gloo: the ctypes callback reduces a host buffer in place (op 0 sum, 1 max)
+    cb = make_allreduce_callback(dist)
+    buf = np.array([1.0 + rank, -2.0 * rank, 7.0], dtype=np.float64)
+    rc_sum = cb(None, buf.ctypes.data_as(C.POINTER(C.c_double)), 3, 0)
+    buf2 = np.array([1.0 + rank, -2.0 * rank, 7.0], dtype=np.float64)
+    rc_max = cb(None, buf2.ctypes.data_as(C.POINTER(C.c_double)), 3, 1)
+    out[rank] = (x, y, rc_sum, buf.copy(), rc_max, buf2.copy())
+    dist.destroy_process_group()
+
+
+def test_row_sharded_iteration_equals_the_unsharded_one_over_gloo():
+    """world-size-2 CPU test of the partition and all-reduce logic of the row-sharded LP: x replicated, y local, A'y = local
+    partial + all-reduce; the iterates are those of the unsharded iteration (up to the summation order of A'y)"""
+    import katana_jl_amd as ktn
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker_rowshard_logic, args=(world, _free_port(), out), nprocs=world, join=True)
+    inst = ktn.instances.make_instance(n=300, m_nl=20, k=8, family="explog", seed=4)
+    A, lo, hi = _lin_block(inst)
+    c = np.zeros(inst.n); c[inst.obj_col] = inst.obj_p0
+    x, y = _pdhg_reflected_halpern(A, c, inst.l_var, inst.u_var, lo, hi, 60, 0.05, 0.05, lambda v: v)
+    assert np.array_equal(out[0][0], out[1][0])                                      # x bit-identical on both ranks
+    assert np.max(np.abs(out[0][0] - x)) <= 1e-13 * max(1.0, np.max(np.abs(x)))
+    ycat = np.concatenate([out[0][1], out[1][1]])                                    # y blocks in rank order = the rows in order
+    assert np.max(np.abs(ycat - y)) <= 1e-13 * max(1.0, np.max(np.abs(y)))
+    for r in range(world):
+        assert out[r][2] == 0 and out[r][4] == 0
+        assert np.array_equal(out[r][3], [3.0, -2.0, 14.0]) and np.array_equal(out[r][5], [2.0, 0.0, 7.0])
+
+
+def _worker_rowshard_gpu(rank, world, port, out, inst_kw):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import katana_jl_amd as ktn
+    from katana_jl_amd.distributed import RowShardedKatanaModel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    inst = ktn.instances.make_instance(**inst_kw)
+    # (a) one LP, tight tolerances: linear rows + the cuts of one sweep at a common point
+    m = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0, purge_age=0, cut_cap_factor=0.0), inst, rank, world, dist)
+    sep = ktn.KatanaHipSeparator(m.m); sep.initialize()
+    sep.precompute(np.clip(inst.xhat + 0.7, inst.l_var, inst.u_var))
+    sep.sweep(1e-6)
+    st, it = m.lp_solve(1e-10, 1e-10)
+    lp = (st, m.getobjval(), m.lp_num_rows(), m.stat("allreduce_calls"), m.transport)
+    # (b) the whole ECP solve
+    m2 = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0), inst, rank, world, dist)
+    status = m2.optimize()
+    out[rank] = (lp, status, m2.getobjval(), m2.getsolution(), m2.numiters(), m2.numcuts_global(), m2.lp_num_rows())
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_row_sharded_lp_equals_the_single_gpu_lp():
+    """2 ranks (both on cuda:0, gloo transport through the host callback): the row-sharded LP reaches the objective of the
+    same LP on one handle to 1e-9, and the row-sharded ECP solve ends at the planted optimum with the same x on both ranks"""
+    import katana_jl_amd as ktn
+    from helpers import hip_load_instance, max_nl_violation, planted_obj_bound
+    world = 2
+    inst_kw = dict(n=400, m_nl=60, k=10, family="explog", seed=11)
+    out = mp.Manager().dict()
+    mp.spawn(_worker_rowshard_gpu, args=(world, _free_port(), out, inst_kw), nprocs=world, join=True)
+    inst = ktn.instances.make_instance(**inst_kw)
+    one = hip_load_instance(ktn, inst, purge_age=0, cut_cap_factor=0.0, lp_dense_after=0)
+    sep = ktn.KatanaHipSeparator(one); sep.initialize()
+    sep.precompute(np.clip(inst.xhat + 0.7, inst.l_var, inst.u_var))
+    sep.sweep(1e-6)
+    st, _ = one.lp_solve(1e-10, 1e-10)
+    assert st == "Optimal"
+    (st0, obj0, rows0, calls0, tr0), (st1, obj1, rows1, calls1, tr1) = out[0][0], out[1][0]
+    assert st0 == st1 == "Optimal" and tr0 == tr1 == "callback" and calls0 == calls1 > 0
+    assert rows0 + rows1 == one.lp_num_rows()                                        # the same rows, split
+    assert obj0 == obj1                                                              # identical on every rank
+    assert abs(obj0 - one.getobjval()) <= 1e-9 * max(1.0, abs(one.getobjval()))
+    # whole solve
+    for r in range(world):
+        assert out[r][1] == "Optimal"
+    assert out[0][2] == out[1][2] and np.array_equal(out[0][3], out[1][3]) and out[0][4] == out[1][4]
+    assert abs(out[0][2] - inst.opt_obj) <= planted_obj_bound(inst)
+    assert max_nl_violation(inst, out[0][3]) <= 1e-6 * (1 + 1e-6)
+    assert out[0][5] == out[1][5] >= inst.m_lin and out[0][6] + out[1][6] >= inst.m_lin

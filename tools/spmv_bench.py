@@ -13,9 +13,9 @@ import numpy as np
 import katana_jl_amd as ktn
 
 
-def build(rows_nl, profile=1, **kw):
+def build(rows_nl, profile=1, device=-1, **kw):
     inst = ktn.instances.make_instance(n=100_000, m_nl=rows_nl, k=32, family="explog", seed=0)
-    m = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, profile=profile, cut_cap_factor=0.0, purge_age=0, **kw))
+    m = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, profile=profile, device=device, cut_cap_factor=0.0, purge_age=0, **kw))
     m.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense, ktn.SeparableNLP(inst))
     sep = ktn.KatanaHipSeparator(m); sep.initialize()
     x = np.clip(inst.xhat + 2.0, inst.l_var, inst.u_var)          # nearly every NL row violated -> one cut per row
