@@ -138,6 +138,9 @@ typedef struct {
                                        iterations, so the default stays lp_ruiz_iters passes from scratch)                    */
     int64_t lp_tiled_nnz;   /* 4000000 LPs with at least this many non-zeros run their SpMVs from tiled copies of the matrix
                                        (input vector staged through LDS in 64 KB blocks); 0 = never     */
+    int32_t lp_near_check;  /* 7       once a check finds row violation, gap and dual residual within 4x their tolerances the next
+                                       check comes after this many iterations instead of lp_check_every (a solve otherwise ends
+                                       on average half a chunk after it converged: -17 % PDHG iterations on cfg3); 0 = off      */
     /* terminal refinement of small problems: once every NL row is within f_tol (the reference's stop rule, src/model.jl:257,273)
        the loop keeps cutting rows that are beyond polish_factor * f_tol, with the LP solved to the matching tolerance.  The
        reference's exact simplex vertices end Kelley's method far below f_tol on its small test models (its suite asserts the
@@ -309,6 +312,14 @@ int ktn_lp_append_rows_nl(ktn_handle h, int64_t nrows, const int64_t* rowptr, co
 int ktn_lp_purge(ktn_handle h, int64_t* rows_removed);
 int ktn_lp_append_rows(ktn_handle h, int64_t nrows, const int64_t* rowptr, const int32_t* col,
                        const double* val, const double* lo, const double* hi);
+
+/* ---- throughput mode (BASELINE.json configs[4]; the loop being batched is src/model.jl:257-309) ---------------------
+ * A batch of independent instances is loaded as ONE block-diagonal problem (variables, rows and the summed linear
+ * objective side by side).  ktn_set_blocks(h, nblocks, col_offsets[nblocks + 1]) -- after ktn_loadproblem -- tells the
+ * engine which column ranges are the instances: every LP re-solve then runs as one launch with one workgroup per instance
+ * (iterates in LDS, __syncthreads() instead of kernel boundaries, restarts and termination decided per instance), while
+ * the sweep and the cut bookkeeping keep serving the whole batch at once.  nblocks = 0 switches it off. */
+int ktn_set_blocks(ktn_handle h, int64_t nblocks, const int64_t* col_offsets);
 
 /* ---- row-sharded LP over several GPUs (no reference counterpart: it splits the LP re-solve of
  * src/model.jl:259 and the cut loop of :272-283 over the ranks) -------------------------------------------------------

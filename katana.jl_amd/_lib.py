@@ -25,7 +25,7 @@ class KtnParams(C.Structure):
                 ("lp_tol_floor", c_f64), ("lp_tol_cap", c_f64), ("lp_gap_floor", c_f64), ("lp_gap_cap", c_f64),
                 ("lp_dual_inherit", c_i32), ("profile", c_i32), ("purge_age", c_i32), ("purge_margin", c_f64),
                 ("purge_min_frac", c_f64), ("purge_min_rows", c_i64), ("lp_dense_after", c_i32), ("cut_cap_factor", c_f64), ("cut_cap_min", c_i64), ("lp_stag_factor", c_f64),
-                ("lp_ruiz_warm", c_i32), ("lp_tiled_nnz", c_i64), ("polish_factor", c_f64), ("polish_max_var", c_i32), ("polish_max_iter", c_i32)]
+                ("lp_ruiz_warm", c_i32), ("lp_tiled_nnz", c_i64), ("lp_near_check", c_i32), ("polish_factor", c_f64), ("polish_max_var", c_i32), ("polish_max_iter", c_i32)]
 
 
 class KtnNlpDesc(C.Structure):
@@ -96,6 +96,7 @@ PROTOTYPES = {
     "ktn_lp_enable_global_lists": (c_i32, [C.c_void_p, c_i64]),
     "ktn_last_sweep_slots": (c_i32, [C.c_void_p, P(c_i64), c_i64, P(c_i64)]),
     "ktn_lp_append_rows_nl": (c_i32, [C.c_void_p, c_i64, P(c_i64), P(c_i32), P(c_f64), P(c_f64), P(c_f64), P(c_i64)]),
+    "ktn_set_blocks": (c_i32, [C.c_void_p, c_i64, P(c_i64)]),
     "ktn_dist_unique_id": (c_i32, [C.c_char_p]),
     "ktn_dist_init_rccl": (c_i32, [C.c_void_p, C.c_char_p, c_i32, c_i32]),
     "ktn_dist_init_callback": (c_i32, [C.c_void_p, c_i32, c_i32, C.c_void_p, C.c_void_p]),

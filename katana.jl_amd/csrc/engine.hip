@@ -27,6 +27,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "dense_lp.hpp"
+#include "batch_lp.hpp"
 #include "prims.hpp"
 
 namespace ktn {
@@ -229,6 +230,10 @@ struct Engine {
     DBuf<uint32_t> p_in, p_out;
     DBuf<char> d_sorttmp;
     DBuf<double> dr_r, dc_r;
+    DBuf<ColRec> d_crec;
+    DBuf<RowRec> d_rrec;
+    DBuf<int2> d_cbl;
+    bool packed_on = false;        // plain steps read packed per-column / per-row records (kernels.hpp)
     DBuf<double> dr, dc, statr, statc, ch, lh, uh, loh, hih, xh, yh, x0h, y0h, xth, yth, xbar, pv, pw, box;
     DBuf<double> partials, chk_part, chkout, power_v;
     // exact small-LP path (dense_lp.hpp)
@@ -259,6 +264,17 @@ struct Engine {
                               T.view(), in, tpart.p);
     }
     bool build_tiled(TiledBuf& T, int64_t n_out, int64_t n_in, const int64_t* ptr, const int32_t* idx, const double* val, int64_t skip_longer);
+    // throughput mode (batch_lp.hpp): the loaded problem is block-diagonal, one workgroup per block runs its LP
+    int64_t n_blocks = 0, blocks_built_rows = -1;
+    std::vector<int64_t> h_blkcol;
+    DBuf<int64_t> d_blkcol;
+    DBuf<int32_t> d_blkrowptr, d_blkrows, d_rowloc, d_crowl;
+    DBuf<double> d_blkomega, d_blkres;
+    int blk_nmax = 0, blk_mmax = 0;
+    void build_blocks();
+    bool lp_solve_blocks(double tol_p, double tol_g, double eta, LpResult* R, int64_t max_it);
+    double smax_prev = 0.0;
+    int64_t smax_rows = 0;
     int64_t scal_rows = 0, scal_cols = 0;   // dr[0, scal_rows) / dc[0, scal_cols) hold the scaling of the last solve
 
     // ---- run state ----
@@ -333,15 +349,16 @@ struct Engine {
     // when the communicator was made by ktn_dist_init_rccl, or a host callback (tests: gloo, ranks sharing one GPU).
     struct DistCtx {
         int rank = 0, world = 1;
+        bool force = false;            // world == 1 but run the collectives anyway (one-rank RCCL test)
         ncclComm_t comm = nullptr;
         ktn_allreduce_cb cb = nullptr;
         void* user = nullptr;
         std::vector<double> hbuf;
     } dist;
     DBuf<double> d_red;            // small device scratch for scalar reductions
-    bool row_sharded() const { return dist.world > 1; }
+    bool row_sharded() const { return dist.world > 1 || dist.force; }
     void allreduce(double* d, size_t n, int op) {          // in place; op 0: sum, 1: max
-        if (dist.world <= 1 || n == 0) return;
+        if (!row_sharded() || n == 0) return;
         stats["allreduce_calls"] += 1.0;
         stats["allreduce_bytes"] += 8.0 * (double)n;
         if (dist.comm) {
@@ -362,7 +379,7 @@ struct Engine {
     }
     // k values reduced over the ranks (host in, host out); every rank gets the identical result
     void allreduce_host(double* v, int k, int op) {
-        if (dist.world <= 1) return;
+        if (!row_sharded()) return;
         d_red.resize(64, stream);
         KTN_REQUIRE(k <= 64, "allreduce_host: too many values");
         KTN_HIP(hipMemcpyAsync(d_red.p, v, (size_t)k * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -607,6 +624,13 @@ struct Engine {
         for (DBuf<double>* b : {&lp_val, &lp_val2, &c_val, &c_sval, &r_sval}) b->reserve(z, stream);
         for (DBuf<int32_t>* b : {&lp_col, &lp_col2, &c_row}) b->reserve(z, stream);
         k_in.reserve(z, stream); k_out.reserve(z, stream); p_in.reserve(z, stream); p_out.reserve(z, stream);
+        // per-solve scratch that would otherwise grow (hipMalloc + copy + hipFree, a device synchronisation each) while the
+        // first solve runs: packed row records, check partials (at most rows / 4 + columns / 4 blocks), sort / scan storage
+        d_rrec.reserve(r, stream);
+        d_crec.reserve((size_t)n_lp + 1, stream); d_cbl.reserve((size_t)n_lp + 1, stream);
+        chk_part.reserve((r / 4 + (size_t)n_lp / 4 + 4096) * kChkQ, stream);
+        d_sorttmp.reserve(sort_pairs_temp_bytes(z) + 16, stream);
+        d_scantmp.reserve(scan_i64_temp_bytes(std::max(r, (size_t)n_lp + 2)) + 16, stream);
     }
     void find_long_rows();
     void launch_y(const SpMat& A, double sigma, double w, double rho, hipEvent_t e0, hipEvent_t e1);
@@ -1073,7 +1097,9 @@ void Engine::reset() {
     d_lastcut.upload(neg1, stream);
     d_age.resize((size_t)std::max<int64_t>(M, 1), stream);
     d_age.zero(stream);
-    lp_dirty = true; have_omega = false; have_precompute = false; sharded_rows = false; scal_rows = 0;
+    lp_dirty = true; have_omega = false; have_precompute = false; sharded_rows = false; scal_rows = 0; smax_rows = 0;
+    blocks_built_rows = -1;
+    if (d_blkomega.n) d_blkomega.zero(stream);
     if (ds_valid.n) ds_valid.zero(stream);
     dense_credit = dense_run = 0;
     if (glists) KTN_HIP(hipMemsetAsync(d_glast.p, 0xFF, d_glast.n * sizeof(int64_t), stream));
@@ -1117,6 +1143,7 @@ void Engine::rebuild_csc() {
         check_launch();
     }
     lp_dirty = false;
+    blocks_built_rows = -1;
 }
 
 // Cut-pool management after an LP solve (k_purge_mark / k_purge_copy / k_purge_relink).
@@ -1168,6 +1195,7 @@ void Engine::purge_cuts() {
     lp_rowptr.n = (size_t)m_new + 1; lp_col.n = lp_val.n = (size_t)nnz_new;
     lp_lo.n = lp_hi.n = lp_y.n = d_age.n = d_cutprev.n = (size_t)m_new;
     if (ds_valid.n) ds_valid.zero(stream);          // row indices changed: the dense path's working set is void
+    smax_rows = 0;
     stats["purged_rows"] += (double)(m - m_new);
     purged_total += m - m_new;
     stats["purges"] += 1.0;
@@ -1270,6 +1298,74 @@ bool Engine::build_tiled(TiledBuf& T, int64_t n_out, int64_t n_in, const int64_t
     return ovf == 0;
 }
 
+// Throughput mode: rows -> blocks (by the first column), block row lists in row order, local row positions of the CSC mirror.
+void Engine::build_blocks() {
+    const int nb = (int)n_blocks;
+    d_blkrowptr.resize((size_t)nb + 1, stream);
+    d_blkrows.resize((size_t)std::max<int64_t>(M, 1), stream);
+    d_rowloc.resize((size_t)std::max<int64_t>(M, 1), stream);
+    d_crowl.resize((size_t)NNZ + 1, stream);
+    k_in.resize((size_t)std::max<int64_t>(M, 1), stream); k_out.resize((size_t)std::max<int64_t>(M, 1), stream);
+    p_in.resize((size_t)std::max<int64_t>(M, 1), stream); p_out.resize((size_t)std::max<int64_t>(M, 1), stream);
+    LAUNCH_1(k_row_block, M, stream, M, lp_rowptr.p, lp_col.p, d_blkcol.p, nb, k_in.p, p_in.p);
+    int bits = 1;
+    while ((1 << bits) < nb + 1 && bits < 30) ++bits;
+    const size_t need = sort_pairs_temp_bytes((size_t)M);
+    d_sorttmp.resize(need + 16, stream);
+    KTN_HIP(sort_pairs_u64_u32(d_sorttmp.p, need, k_in.p, k_out.p, p_in.p, p_out.p, (size_t)M, 0, bits, stream));   // stable: rows ascending
+    LAUNCH_1(k_block_rows, M, stream, M, k_out.p, p_out.p, nb, d_blkrowptr.p, d_blkrows.p, d_rowloc.p);
+    LAUNCH_1(k_row_local, M, stream, M, k_out.p, p_out.p, d_blkrowptr.p, d_rowloc.p);
+    LAUNCH_1(k_localize_rows, NNZ, stream, NNZ, c_row.p, d_rowloc.p, d_crowl.p);
+    check_launch();
+    std::vector<int32_t> rp = d_blkrowptr.to_host(stream);
+    blk_mmax = 1;
+    for (int b = 0; b < nb; ++b) blk_mmax = std::max(blk_mmax, rp[(size_t)b + 1] - rp[(size_t)b]);
+    blocks_built_rows = M;
+}
+
+// One launch: every block's LP to the given tolerances.  Returns false when some block could not finish here (the caller
+// then runs the ordinary loop).
+bool Engine::lp_solve_blocks(double tol_p, double tol_g, double eta, LpResult* R, int64_t max_it) {
+    const int nb = (int)n_blocks;
+    const size_t lds = (size_t)(3 * blk_nmax + 3 * blk_mmax + (kBlkThreads / 64) * kBlkQ + kBlkQ + 8) * sizeof(double) +
+                       (size_t)(blk_mmax + 2) * sizeof(int32_t);
+    if (lds > 150 * 1024) return false;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        KTN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pdhg_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    d_blkres.resize((size_t)nb * 8, stream);
+    BlkLp P;
+    P.blk_col = d_blkcol.p; P.blk_rowptr = d_blkrowptr.p; P.blk_rows = d_blkrows.p;
+    P.rptr = lp_rowptr.p; P.rcol = lp_col.p; P.rval = r_sval.p;
+    P.cptr = c_ptr.p; P.crowl = d_crowl.p; P.cval = c_sval.p;
+    P.c = ch.p; P.l = lh.p; P.u = uh.p; P.lo = loh.p; P.hi = hih.p; P.dr = dr.p; P.dc = dc.p;
+    P.x = xh.p; P.y = yh.p; P.xt = xth.p; P.yt = yth.p; P.omega = d_blkomega.p; P.res = d_blkres.p;
+    P.tol_p = tol_p; P.tol_g = tol_g; P.eta0 = eta; P.eta_safe = 0.998; P.stag_factor = prm.lp_stag_factor;
+    P.stall_accept = (tol_p > prm.lp_tol_floor * prm.f_tol * (1.0 + 1e-9)) ? 10.0 : 2.0;
+    P.check_every = std::max(2, prm.lp_check_every); P.first_chunk = 31; P.near_chunk = prm.lp_near_check;
+    P.max_iter = (int)std::min<int64_t>(max_it, 2000000000);
+    P.nmax = blk_nmax; P.mmax = blk_mmax;
+    hipLaunchKernelGGL(k_pdhg_blocks, dim3((unsigned)nb), dim3(kBlkThreads), lds, stream, P);
+    check_launch();
+    std::vector<double> res = d_blkres.to_host(stream);
+    bool all_ok = true;
+    double pobj = 0.0, dobj = 0.0, pviol = 0.0, gap = 0.0, it_max = 0.0, it_sum = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        const double* o = res.data() + (size_t)b * 8;
+        if ((int)o[0] != KTN_STATUS_OPTIMAL) all_ok = false;
+        pobj += o[2]; dobj += o[3]; pviol = std::max(pviol, o[4]); gap = std::max(gap, o[5]);
+        it_max = std::max(it_max, o[1]); it_sum += o[1];
+    }
+    stats["blk_lp_launches"] += 1.0;
+    stats["blk_pdhg_iters_sum"] += it_sum;
+    stats["blk_pdhg_iters_max"] += it_max;
+    if (!all_ok) { stats["blk_lp_fallbacks"] += 1.0; return false; }
+    R->status = KTN_STATUS_OPTIMAL; R->iters = (int64_t)it_max; R->pobj = pobj; R->dobj = dobj; R->row_viol = pviol; R->gap = gap;
+    return true;
+}
+
 void Engine::find_long_rows() {
     n_long = 0;
     if (M == 0) return;
@@ -1304,6 +1400,10 @@ void Engine::launch_y(const SpMat& A, double sigma, double w, double rho, hipEve
         hipExtLaunchKernelGGL(k_y_epilogue, dim3(ceil_div(m, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, m, tA.pcnt.p,
                               tpart.p, (n_long > 0 ? A.ptr : (const int64_t*)nullptr), thr, yh.p, y0h.p,
                               loh.p, hih.p, sigma, w, rho);
+    } else if (packed_on) {
+        const int thr32 = n_long > 0 ? (int)kLongRow : 0x7fffffff;
+        if (e0) LAUNCH_G_EV(grp_rows, k_pdhg_y_packed, m, stream, e0, e1, m, A.idx, A.val, xbar.p, yh.p, d_rrec.p, sigma, w, rho, thr32);
+        else LAUNCH_G(grp_rows, k_pdhg_y_packed, m, stream, m, A.idx, A.val, xbar.p, yh.p, d_rrec.p, sigma, w, rho, thr32);
     } else if (e0) {
         LAUNCH_G_EV(grp_rows, k_pdhg_y, m, stream, e0, e1, m, A, xbar.p, yh.p, y0h.p, loh.p, hih.p, sigma, w, rho, thr);
     } else {
@@ -1330,6 +1430,9 @@ void Engine::launch_x(const SpMat& AT, double tau, double w, double rho, bool up
             launch_tiled(tAT, n, M, yh.p, e0);
             hipExtLaunchKernelGGL(k_x_epilogue, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, n, tAT.pcnt.p,
                                   tpart.p, xh.p, x0h.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        } else if (packed_on) {
+            if (e0) LAUNCH_G_EV(grp_cols, k_pdhg_x_packed, n, stream, e0, e1, n, d_cbl.p, AT.idx, AT.val, yh.p, xh.p, xbar.p, d_crec.p, tau, w, rho);
+            else LAUNCH_G(grp_cols, k_pdhg_x_packed, n, stream, n, d_cbl.p, AT.idx, AT.val, yh.p, xh.p, xbar.p, d_crec.p, tau, w, rho);
         } else if (e0) {
             LAUNCH_GB_EV(grp_cols, k_pdhg_x, true, n, stream, e0, e1, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
         } else {
@@ -1366,7 +1469,7 @@ void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double si
         LAUNCH_G(grp_cols, k_chk_cols, n, stream, n, AT, xh.p, xth.p, x0h.p, yth.p, ch.p, lh.p, uh.p, dc.p, pcol);
         chk_ncol = (int)bcol;
     }
-    hipLaunchKernelGGL(k_chk_final, dim3(2), dim3(kRedBlocks), 0, stream, prow, chk_nrow, pcol, chk_ncol, chkout.p);   // rows | columns
+    hipLaunchKernelGGL(k_chk_final, dim3(2 * kChkQ), dim3(kRedBlocks), 0, stream, prow, chk_nrow, pcol, chk_ncol, chkout.p);   // (rows | columns) x quantity
     if (row_sharded()) {                            // row sums: every rank's rows; column sums are identical already
         allreduce(chkout.p, 12, 0);
         allreduce(chkout.p + 12, 4, 1);
@@ -1513,7 +1616,13 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     // last ||A^||_2 <= 1 is guaranteed (Pock & Chambolle 2011, Lemma 2): eta_safe = 0.998; always using
     // it costs 40 % (cfg3) to 170 % (cfg2) more PDHG iterations than the estimate.
     double smax = 0.0;
-    if ((m > 0 && NNZ > 0) || row_sharded()) {
+    // sigma_max of the previous solve is reused while the matrix has grown by less than KTN_SMAX_REUSE (a fraction of its
+    // rows) since the estimate was made (development switch, default off)
+    static const double smax_reuse = std::getenv("KTN_SMAX_REUSE") ? std::atof(std::getenv("KTN_SMAX_REUSE")) : 0.0;
+    const bool reuse_smax = mode == 0 && smax_reuse > 0.0 && smax_rows > 0 && m >= smax_rows && !row_sharded() &&
+                            (double)(m - smax_rows) <= smax_reuse * (double)smax_rows && smax_prev > 0.0;
+    if (reuse_smax) { smax = smax_prev; stats["lp_smax_reused"] += 1.0; }
+    else if ((m > 0 && NNZ > 0) || row_sharded()) {
         // 20 passes from a hashed start vector.  Norms stay on the device (k_normalize reads them): one host
         // round trip at the end instead of one per pass.  (Measured: warm-starting v from the previous LP makes
         // the estimate tighter and the step therefore smaller -- cfg3 then needs 14 700 instead of 7 800 PDHG
@@ -1550,6 +1659,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         KTN_HIP(hipMemcpyAsync(&nv2, nrm, 8, hipMemcpyDeviceToHost, stream));
         sync();
         smax = (nv2 > 0.0) ? std::sqrt(std::sqrt(nv2)) : 0.0;     // sigma_max^2 ~ ||A'A v||
+        if (mode == 0) { smax_prev = smax; smax_rows = m; }
     }
     lap("lp_power_time_s", tp);
     double fro2 = (NNZ > 0) ? dev_dot(NNZ, r_sval.p, r_sval.p) : 0.0;                  // ||A||_2 <= ||A||_F
@@ -1571,8 +1681,17 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     const double rho = 1.0;
     const double cinf_scale = 1.0;
 
-    KTN_HIP(hipMemcpyAsync(x0h.p, xh.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
-    if (m > 0) KTN_HIP(hipMemcpyAsync(y0h.p, yh.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    // anchors z0 = z; with the packed records of the plain steps (not for the tiled / row-sharded forms, whose steps are
+    // split into SpMV + element-wise kernels)
+    packed_on = !tiled_on && !row_sharded() && NNZ < ((int64_t)1 << 31) && std::getenv("KTN_NO_PACKED") == nullptr;
+    if (packed_on) {
+        d_crec.resize((size_t)n, stream); d_cbl.resize((size_t)n, stream); d_rrec.resize(mm, stream);
+        LAUNCH_1(k_pack_cols, n, stream, n, c_ptr.p, ch.p, lh.p, uh.p, xh.p, x0h.p, d_crec.p, d_cbl.p);
+        LAUNCH_1(k_pack_rows, m, stream, m, lp_rowptr.p, loh.p, hih.p, yh.p, y0h.p, d_rrec.p);
+    } else {
+        KTN_HIP(hipMemcpyAsync(x0h.p, xh.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        if (m > 0) KTN_HIP(hipMemcpyAsync(y0h.p, yh.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    }
 
     const double ky_bytes = (double)NNZ * 12 + 8.0 * (m + 1) + 8.0 * 5 * m + 8.0 * n;
     const double kx_bytes = (double)NNZ * 12 + 8.0 * (n + 1) + 8.0 * 7 * n + 8.0 * m;
@@ -1584,15 +1703,27 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     const int chk = std::max(1, prm.lp_check_every);
     const int plain_len = std::min(chk - 1, (int)kMaxChunk);
     static const int first_chunk = std::getenv("KTN_FIRST_CHUNK") ? std::atoi(std::getenv("KTN_FIRST_CHUNK")) : 31;
-    bool plain_next = false;
-    while (it < max_it) {
+    bool plain_next = false, near_conv = false;
+    // throughput mode: one workgroup per block runs its LP to the end (batch_lp.hpp); the ordinary loop below only serves
+    // as the fall-back when a block reports that it could not finish
+    bool blocks_done = false;
+    if (n_blocks > 0 && mode == 0 && !row_sharded() && n_long == 0 && m > 0 && !prm.profile) {
+        if (blocks_built_rows != M) build_blocks();
+        blocks_done = lp_solve_blocks(tol_p, tol_g, eta, &R, max_it);
+        if (blocks_done) it = R.iters;
+    }
+    static const int near_env = std::getenv("KTN_NEAR_CHUNK") ? std::atoi(std::getenv("KTN_NEAR_CHUNK")) : -1;
+    const int near_chunk = near_env >= 0 ? near_env : prm.lp_near_check;
+    while (!blocks_done && it < max_it) {
         const double tau = eta / om, sigma = eta * om;
         if (plain_next) {
             // ---- a chunk of plain (update) iterations between two checks
             plain_next = false;
             // the first chunk after a restart is shorter: the restarted iteration moves fastest there and an
             // early check catches the next restart / termination sooner
-            const int want = (k <= 1 && first_chunk > 0) ? std::min(first_chunk, plain_len) : plain_len;
+            int want = (k <= 1 && first_chunk > 0) ? std::min(first_chunk, plain_len) : plain_len;
+            // close to the tolerances the next check comes sooner: a solve ends on average half a chunk after it converged
+            if (near_conv && near_chunk > 0) want = std::min(want, near_chunk);
             const int np = (int)std::min<int64_t>(want, max_it - it);
             if (np <= 0) continue;
             for (int j = 0; j < np; ++j) {
@@ -1630,6 +1761,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
                                  mode, (long long)it, (long long)k, r, pviol, dres, gap, pobj, dobj, om, eta);
         R.pobj = pobj; R.dobj = dobj; R.row_viol = pviol; R.gap = gap;
         bool done = (pviol <= tol_p) && (gap <= tol_g) && (dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2)));
+        near_conv = (pviol <= 4.0 * tol_p) && (gap <= 4.0 * tol_g) && (dres * cinf_scale <= 4.0 * tol_g * (1.0 + std::sqrt(nc2)));
         // Primal-stagnation exit (lp_stag_factor).  On LPs with degenerate duals the primal part converges within a few
         // hundred iterations while the duality gap crawls for 10 000 more: stop when the rows are
         // feasible to tol_p, the dual residual is converged, the primal objective has not moved by more than 0.1 tol_g
@@ -1708,7 +1840,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
                 KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
                 LAUNCH_1(k_consolidate, list_count(), stream, list_count(), list_heads(), d_cutprev.p, pw.p, lp_lo.p, lp_hi.p, dr.p, tol_p, yth.p,
                          d_anynf.p + 1);
-                LAUNCH_1(k_restart_set, std::max(n, m), stream, n, m, xth.p, xh.p, x0h.p, yth.p, yh.p, y0h.p);
+                LAUNCH_1(k_restart_set, std::max(n, m), stream, n, m, xth.p, xh.p, x0h.p, yth.p, yh.p, y0h.p, packed_on ? d_crec.p : (ColRec*)nullptr,
+                         packed_on ? d_rrec.p : (RowRec*)nullptr);
                 k = 0;
                 r_last_check = 0.0;
                 ++it;
@@ -1726,7 +1859,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
                 om = std::exp(0.5 * std::log(dy / dx) + 0.5 * std::log(om));
                 om = std::min(std::max(om, omega_ref * 1e-3), omega_ref * 1e3);
             }
-            LAUNCH_1(k_restart_set, std::max(n, m), stream, n, m, xth.p, xh.p, x0h.p, yth.p, yh.p, y0h.p);
+            LAUNCH_1(k_restart_set, std::max(n, m), stream, n, m, xth.p, xh.p, x0h.p, yth.p, yh.p, y0h.p, packed_on ? d_crec.p : (ColRec*)nullptr,
+                         packed_on ? d_rrec.p : (RowRec*)nullptr);
             stats["lp_restarts"] += 1.0;
             k = 0;
             ++it;
@@ -1775,6 +1909,7 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
     grp_cols = pick_group(n ? (double)NNZ / (double)n : 1.0);
     SpMat A{lp_rowptr.p, lp_col.p, r_sval.p};
     SpMat AT{c_ptr.p, c_row.p, c_sval.p};
+    packed_on = false;
     KTN_HIP(hipMemcpyAsync(x0h.p, xh.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     if (m > 0) KTN_HIP(hipMemcpyAsync(y0h.p, yh.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
     find_long_rows();
@@ -2045,7 +2180,7 @@ void ktn_default_params(ktn_params* p) {
     p->lp_dense_after = 5000;
     p->cut_cap_factor = 2.0; p->cut_cap_min = 10000;
     p->lp_stag_factor = 100.0;
-    p->lp_ruiz_warm = 0; p->lp_tiled_nnz = 4000000;
+    p->lp_ruiz_warm = 0; p->lp_tiled_nnz = 4000000; p->lp_near_check = 7;
     p->polish_factor = 1e-3; p->polish_max_var = 32; p->polish_max_iter = 30;
 }
 
@@ -2378,6 +2513,30 @@ int ktn_lp_purge(ktn_handle h, int64_t* rows_removed) {
         return KTN_OK;
     })
 }
+// ---- throughput mode: the loaded problem is a block-diagonal batch of independent instances
+int ktn_set_blocks(ktn_handle h, int64_t nblocks, const int64_t* col_offsets) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && nblocks >= 0, "ktn_set_blocks: after loadproblem");
+        if (nblocks == 0) { e->n_blocks = 0; return KTN_OK; }
+        KTN_REQUIRE(col_offsets && e->obj_linear, "ktn_set_blocks: needs a linear objective (no shared epigraph variable)");
+        KTN_REQUIRE(col_offsets[0] == 0 && col_offsets[nblocks] == e->n_lp, "ktn_set_blocks: offsets must cover the columns");
+        e->h_blkcol.assign(col_offsets, col_offsets + nblocks + 1);
+        e->blk_nmax = 1;
+        for (int64_t b = 0; b < nblocks; ++b) {
+            KTN_REQUIRE(col_offsets[b + 1] >= col_offsets[b], "ktn_set_blocks: offsets not monotone");
+            e->blk_nmax = std::max<int>(e->blk_nmax, (int)(col_offsets[b + 1] - col_offsets[b]));
+        }
+        e->d_blkcol.upload(e->h_blkcol, e->stream);
+        e->d_blkomega.resize((size_t)nblocks, e->stream);
+        e->d_blkomega.zero(e->stream);
+        e->sync();
+        e->n_blocks = nblocks;
+        e->blocks_built_rows = -1;
+        return KTN_OK;
+    })
+}
+
 // ---- row-sharded LP over several GPUs
 int ktn_dist_unique_id(char* out128) {
     if (!out128) return KTN_E_INVALID;
@@ -2393,7 +2552,8 @@ int ktn_dist_init_rccl(ktn_handle h, const char* uid128, int32_t rank, int32_t w
         KTN_REQUIRE(!e->loaded, "ktn_dist_init_*: call before loadproblem");
         KTN_REQUIRE(uid128 && world >= 1 && rank >= 0 && rank < world, "ktn_dist_init_rccl: bad rank / world");
         e->dist.rank = rank; e->dist.world = world;
-        if (world > 1) {
+        e->dist.force = world == 1 && std::getenv("KTN_FORCE_COLLECTIVE") != nullptr;
+        if (world > 1 || e->dist.force) {
             ncclUniqueId id;
             std::memcpy(id.internal, uid128, 128);
             KTN_HIP(hipSetDevice(e->device));

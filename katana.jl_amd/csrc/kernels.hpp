@@ -630,13 +630,17 @@ struct ChkAcc {
     }
 };
 // every thread of the block must call this (it holds a barrier); fixed-shape reduction: butterfly per wavefront,
-// then the block's wavefronts in order
-template <int BLOCK>
+// then the block's wavefronts in order.  MASK: the quantities this side of the check accumulates (the others are
+// written as zeros without being reduced).
+constexpr unsigned kChkRowMask = 0x141Fu;     // s0-s4, s10, m12
+constexpr unsigned kChkColMask = 0x6FE0u;     // s5-s11, m13, m14
+template <int BLOCK, unsigned MASK>
 __device__ __forceinline__ void chk_block_store(ChkAcc& a, double* partials) {
     __shared__ double sh[kChkQ][BLOCK / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < kChkQ; ++q) {
+        if (!((MASK >> q) & 1u)) continue;
         double v = a.s[q];
         if (q < 12) v = group_sum<64>(v); else v = group_max<64>(v);
         if (lane == 0) sh[q][wv] = v;
@@ -644,8 +648,11 @@ __device__ __forceinline__ void chk_block_store(ChkAcc& a, double* partials) {
     __syncthreads();
     if (threadIdx.x < kChkQ) {
         const int q = threadIdx.x;
-        double v = sh[q][0];
-        for (int k = 1; k < BLOCK / 64; ++k) v = (q < 12) ? v + sh[q][k] : fmax(v, sh[q][k]);
+        double v = 0.0;
+        if ((MASK >> q) & 1u) {
+            v = sh[q][0];
+            for (int k = 1; k < BLOCK / 64; ++k) v = (q < 12) ? v + sh[q][k] : fmax(v, sh[q][k]);
+        }
         partials[(int64_t)blockIdx.x * kChkQ + q] = v;
     }
 }
@@ -674,6 +681,77 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_x(int64_t n, SpMat AT, const do
         const double xtv = clampd(xv - tau * (cj - acc), lj, uj);
         if (UPDATE) { xbar[j] = 2.0 * xtv - xv; x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0j; }
         else xt[j] = xtv;
+    }
+}
+
+// ---- packed operands of the plain (update) steps ----------------------------------------------------------------
+// Per column the x-step reads (beg, len) as one 8-byte pair and (c, l, u, x0) as one 32-byte record instead of seven
+// separate arrays; per row the y-step reads (lo, hi, y0, beg | len) as one 32-byte record.  The records mirror ch / lh /
+// uh / x0h and loh / hih / y0h (which the check kernels keep using) and are rewritten where those change: at the start
+// of a solve (k_pack_cols / k_pack_rows) and at restarts (k_restart_set).
+struct __attribute__((aligned(32))) ColRec { double c, l, u, x0; };
+struct __attribute__((aligned(32))) RowRec { double lo, hi, y0; int32_t beg, len; };
+
+__global__ __launch_bounds__(kBlock) void k_pack_cols(int64_t n, const int64_t* __restrict__ ptr, const double* __restrict__ c,
+                                                      const double* __restrict__ l, const double* __restrict__ u,
+                                                      const double* __restrict__ x, double* __restrict__ x0,
+                                                      ColRec* __restrict__ rec, int2* __restrict__ bl) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    const double xv = x[j];
+    x0[j] = xv;
+    ColRec r; r.c = c[j]; r.l = l[j]; r.u = u[j]; r.x0 = xv;
+    rec[j] = r;
+    bl[j] = make_int2((int)ptr[j], (int)(ptr[j + 1] - ptr[j]));
+}
+__global__ __launch_bounds__(kBlock) void k_pack_rows(int64_t m, const int64_t* __restrict__ ptr, const double* __restrict__ lo,
+                                                      const double* __restrict__ hi, const double* __restrict__ y,
+                                                      double* __restrict__ y0, RowRec* __restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const double yv = y[i];
+    y0[i] = yv;
+    RowRec r; r.lo = lo[i]; r.hi = hi[i]; r.y0 = yv; r.beg = (int32_t)ptr[i]; r.len = (int32_t)(ptr[i + 1] - ptr[i]);
+    rec[i] = r;
+}
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_pdhg_x_packed(int64_t n, const int2* __restrict__ bl, const int32_t* __restrict__ idx,
+                                                          const double* __restrict__ val, const double* __restrict__ y,
+                                                          double* __restrict__ x, double* __restrict__ xbar,
+                                                          const ColRec* __restrict__ rec, double tau, double w, double rho) {
+    const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (j >= n) return;
+    const int2 b = bl[j];
+    const ColRec r = rec[j];
+    const double xv = x[j];
+    double acc = 0.0;
+    for (int e = b.x + lane; e < b.x + b.y; e += G) acc += val[e] * y[idx[e]];
+    acc = group_sum<G>(acc);
+    if (lane == 0) {
+        const double xtv = clampd(xv - tau * (r.c - acc), r.l, r.u);
+        xbar[j] = 2.0 * xtv - xv;
+        x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * r.x0;
+    }
+}
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_pdhg_y_packed(int64_t m, const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                          const double* __restrict__ xbar, double* __restrict__ y,
+                                                          const RowRec* __restrict__ rec, double sigma, double w, double rho,
+                                                          int long_thresh) {
+    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (i >= m) return;
+    const RowRec r = rec[i];
+    if (r.len > long_thresh) return;              // served by k_pdhg_y_long (a workgroup per row)
+    const double yv = y[i];
+    double acc = 0.0;
+    for (int e = r.beg + lane; e < r.beg + r.len; e += G) acc += val[e] * xbar[idx[e]];
+    acc = group_sum<G>(acc);
+    if (lane == 0) {
+        const double v = yv - sigma * acc;
+        const double ytv = v + sigma * clampd(-v / sigma, r.lo, r.hi);
+        y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * r.y0;
     }
 }
 
@@ -754,7 +832,7 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_y_chk(int64_t m, SpMat A, const
         yt[i] = ytv;
         chk_row_accumulate(a, ytv, yv, y0i, axt, axk, loi, hii, dri);
     }
-    chk_block_store<kBlock>(a, partials);
+    chk_block_store<kBlock, kChkRowMask>(a, partials);
 }
 
 // Long rows (dense epigraph cuts: n+1 entries): one 1024-thread workgroup per row, fixed-shape
@@ -808,13 +886,15 @@ __global__ __launch_bounds__(kBlock) void k_find_long(int64_t m, const int64_t* 
     if (rowptr[i + 1] - rowptr[i] > thresh) list[atomicAdd(count, 1)] = (int32_t)i;
 }
 
-// Restart: z <- T(z), anchor z0 <- T(z), primal and dual part in one launch (instead of four device-to-device copies).
+// Restart: z <- T(z), anchor z0 <- T(z), primal and dual part in one launch (instead of four device-to-device copies);
+// the packed records of the plain steps carry x0 / y0 too.
 __global__ __launch_bounds__(kBlock) void k_restart_set(int64_t n, int64_t m, const double* __restrict__ xt, double* __restrict__ x,
                                                        double* __restrict__ x0, const double* __restrict__ yt,
-                                                       double* __restrict__ y, double* __restrict__ y0) {
+                                                       double* __restrict__ y, double* __restrict__ y0,
+                                                       ColRec* __restrict__ crec, RowRec* __restrict__ rrec) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) { const double v = xt[i]; x[i] = v; x0[i] = v; }
-    if (i < m) { const double v = yt[i]; y[i] = v; y0[i] = v; }
+    if (i < n) { const double v = xt[i]; x[i] = v; x0[i] = v; if (crec) crec[i].x0 = v; }
+    if (i < m) { const double v = yt[i]; y[i] = v; y0[i] = v; if (rrec) rrec[i].y0 = v; }
 }
 // Halpern update of the primal and the dual part in one launch (after a check iteration that neither terminated nor
 // restarted); also refreshes xbar = 2 xt - x_old for nobody: the next x-step recomputes it
@@ -826,32 +906,28 @@ __global__ __launch_bounds__(kBlock) void k_halpern2(int64_t n, int64_t m, doubl
     if (i < m) y[i] = w * ((1.0 + rho) * yt[i] - rho * y[i]) + (1.0 - w) * y0[i];
 }
 
-// second stage of the deterministic reductions: ONE block of kRedBlocks threads per side; thread b owns the partial
-// blocks b, b + kRedBlocks, ... in that order (coalesced loads), then a fixed-shape butterfly + LDS tree -> run-to-run
-// identical sums.  blockIdx.x selects the side (0: rows, 1: columns): both reductions in ONE launch.
+// second stage of the deterministic reductions: one block of kRedBlocks threads per (side, quantity) -- blockIdx.x =
+// side * kChkQ + q, side 0: rows, 1: columns -- thread b owns the partial blocks b, b + kRedBlocks, ... in that order,
+// then a fixed-shape butterfly + LDS tree -> run-to-run identical sums.
 __global__ __launch_bounds__(kRedBlocks) void k_chk_final(const double* __restrict__ prow, int nrow, const double* __restrict__ pcol,
                                                           int ncol, double* __restrict__ out) {
-    __shared__ double sh[kChkQ][kRedBlocks / 64];
-    const double* partials = blockIdx.x ? pcol : prow;
-    const int nblocks = blockIdx.x ? ncol : nrow;
-    out += (int64_t)blockIdx.x * kChkQ;
+    __shared__ double sh[kRedBlocks / 64];
+    const int side = blockIdx.x / kChkQ, q = blockIdx.x - side * kChkQ;
+    const double* partials = side ? pcol : prow;
+    const int nblocks = side ? ncol : nrow;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int q = 0; q < kChkQ; ++q) {
-        double v = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += kRedBlocks) {
-            const double p = partials[(int64_t)b * kChkQ + q];
-            v = (q < 12) ? v + p : fmax(v, p);
-        }
-        v = (q < 12) ? group_sum<64>(v) : group_max<64>(v);
-        if (lane == 0) sh[q][wv] = v;
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += kRedBlocks) {
+        const double p = partials[(int64_t)b * kChkQ + q];
+        v = (q < 12) ? v + p : fmax(v, p);
     }
+    v = (q < 12) ? group_sum<64>(v) : group_max<64>(v);
+    if (lane == 0) sh[wv] = v;
     __syncthreads();
-    if (threadIdx.x < kChkQ) {
-        const int q = threadIdx.x;
-        double v = sh[q][0];
-        for (int k = 1; k < kRedBlocks / 64; ++k) v = (q < 12) ? v + sh[q][k] : fmax(v, sh[q][k]);
-        out[q] = v;
+    if (threadIdx.x == 0) {
+        double r = sh[0];
+        for (int k = 1; k < kRedBlocks / 64; ++k) r = (q < 12) ? r + sh[k] : fmax(r, sh[k]);
+        out[side * kChkQ + q] = r;
     }
 }
 
@@ -893,7 +969,7 @@ __global__ __launch_bounds__(kBlock) void k_chk_cols(int64_t n, SpMat AT, const 
         if (r0 > 0.0) { if (isfinite(lj)) { a.s[10] += lj * r0; a.s[11] += fabs(lj * r0); } else a.s[14] = fmax(a.s[14], r0); }
         else if (r0 < 0.0) { if (isfinite(uj)) { a.s[10] += uj * r0; a.s[11] += fabs(uj * r0); } else a.s[14] = fmax(a.s[14], -r0); }
     }
-    chk_block_store<kBlock>(a, partials);
+    chk_block_store<kBlock, kChkColMask>(a, partials);
 }
 
 // ================================================== LP: row-sharded over several GPUs ===============================
@@ -937,7 +1013,7 @@ __global__ __launch_bounds__(kBlock) void k_chk_cols_vec(int64_t n, const double
         if (r0 > 0.0) { if (isfinite(lj)) { a.s[10] += lj * r0; a.s[11] += fabs(lj * r0); } else a.s[14] = fmax(a.s[14], r0); }
         else if (r0 < 0.0) { if (isfinite(uj)) { a.s[10] += uj * r0; a.s[11] += fabs(uj * r0); } else a.s[14] = fmax(a.s[14], -r0); }
     }
-    chk_block_store<kBlock>(a, partials);
+    chk_block_store<kBlock, kChkColMask>(a, partials);
 }
 
 // ================================================== LP: tiled SpMV for LPs beyond the caches =========================

@@ -137,6 +137,11 @@ class KatanaNonlinearModel:
         self._lib.ktn_setwarmstart(self._h, _p(x), len(x))
         return np.zeros(len(x))
 
+    def set_blocks(self, col_offsets):
+        """throughput mode: the loaded problem is block-diagonal with these column offsets (ktn_set_blocks)"""
+        off = np.ascontiguousarray(col_offsets, dtype=np.int64)
+        L.check(self._h, self._lib.ktn_set_blocks(self._h, len(off) - 1, _p(off, C.c_int64)))
+
     def stat(self, name):
         return float(self._lib.ktn_get_stat(self._h, name.encode()))
 

@@ -229,3 +229,21 @@ def test_stalled_row_violation_is_accepted_below_twice_the_row_tolerance():
     assert m.stat("pdhg_iters") < 200000
     assert abs(m.getobjval() - inst.opt_obj) <= 1e-7 * max(1.0, abs(inst.opt_obj))
     assert max_nl_violation(inst, m.getsolution()[:inst.n]) <= 1e-6 * (1 + 1e-6)
+
+
+def test_full_batch_of_512_cfg5_instances_one_workgroup_per_instance():
+    """BASELINE.json configs[4] at full size: 512 independent 1e3-variable instances as one block-diagonal problem whose LP
+    re-solves run as ONE launch with one workgroup per instance (ktn_set_blocks, csrc/batch_lp.hpp); every instance ends at
+    its own planted optimum, within f_tol, and the per-instance LP path really ran (no fall-back to the global loop)"""
+    insts = [ktn.instances.make_config("cfg5_one", seed=s) for s in range(512)]
+    res, wall = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts, fused=True, per_instance_lp=True)
+    assert len(res) == 512 and res[0]["blk_lp_launches"] >= 2 and res[0]["blk_lp_fallbacks"] == 0
+    for r, inst in zip(res, insts):
+        assert r["status"] == "Optimal"
+        assert abs(r["objval"] - inst.opt_obj) <= planted_obj_bound(inst)
+        assert max_nl_violation(inst, r["x"]) <= 1e-6 * (1 + 1e-6)
+        assert np.max(np.abs(r["x"] - inst.xhat)) <= 1e-3
+    # the same batch through the global first-order loop: the same answers up to the stop rule
+    ref, _ = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts[:64], fused=True, per_instance_lp=False)
+    for a, b, inst in zip(res[:64], ref, insts[:64]):
+        assert abs(a["objval"] - b["objval"]) <= planted_obj_bound(inst)
