@@ -251,7 +251,7 @@ def main():
         sweep_roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                           "kernel": "k_sep_eval_blk + k_sep_combine (column-blocked separator sweep)",
                           "workload": "cfg3_hbm: n=%d, m_nl=%d exp/log rows, k=%d" % (hb.n, hb.m_nl, hb.meta["k"]),
-                          "launches": int(dn), "avg_launch_us": 1e6 * dt / dn, "algorithmic_bytes_per_launch": db / dn}
+                          "launches": int(dn), "avg_launch_us": 1e6 * dt / dn, "algorithmic_bytes_per_launch": db / dn, "traffic": None}
         tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
             t = json.load(open(tpath)).get("k_sep_eval_blk")
@@ -273,7 +273,7 @@ def main():
         b0 = {k: sm.stat(k) for k in keys}
         sm.lp_pdhg_raw(x0, y0, 1e-3, 1.0, 40)
         dd = {k: sm.stat(k) - b0[k] for k in keys}
-        spmv_roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        spmv_roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                          "workload": "cfg4 LP after one un-capped sweep: n=%d, rows=%d (%d cuts), nnz=%d: CSR + CSC mirror %.0f MB" % (
                              sinst.n, M, nviol, nnz, 2 * nnz * 12 / 1e6),
                          "tiled": bool(sm.stat("lp_tiled_builds")), "kernels": {}}
@@ -283,6 +283,12 @@ def main():
                                               "achieved": by / tt / 1e9, "frac": by / tt / 1e9 / HBM_PEAK_GBS}
         worst = min(spmv_roofline["kernels"].values(), key=lambda r: r["frac"])
         spmv_roofline["achieved"], spmv_roofline["frac"] = worst["achieved"], worst["frac"]
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath)).get("k_spmv_tiled")
+            if t:
+                spmv_roofline["traffic"] = t["bytes_per_launch"]
+                spmv_roofline["traffic_source"] = "profiles/r02_traffic.json (k_spmv_tiled alone; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         del sm, sinst
 
     cpu = None

@@ -141,6 +141,9 @@ typedef struct {
     int32_t lp_near_check;  /* 7       once a check finds row violation, gap and dual residual within 4x their tolerances the next
                                        check comes after this many iterations instead of lp_check_every (a solve otherwise ends
                                        on average half a chunk after it converged: -17 % PDHG iterations on cfg3); 0 = off      */
+    double  dedupe_eps;     /* 1e-6    at every purge pass, cuts of an NL row that agree with the row's newest cut within this relative
+                                       tolerance (coefficients and bound, normalised by the largest coefficient) are dropped and
+                                       their multipliers moved to the newest cut (the reference's TODO, src/model.jl:215); 0 = off */
     /* terminal refinement of small problems: once every NL row is within f_tol (the reference's stop rule, src/model.jl:257,273)
        the loop keeps cutting rows that are beyond polish_factor * f_tol, with the LP solved to the matching tolerance.  The
        reference's exact simplex vertices end Kelley's method far below f_tol on its small test models (its suite asserts the

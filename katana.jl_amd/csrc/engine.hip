@@ -1154,6 +1154,15 @@ void Engine::purge_cuts() {
     d_newidx.resize((size_t)m, stream); d_newptr.resize((size_t)m, stream);
     LAUNCH_1(k_purge_mark, m, stream, M_base, m, lp_rowptr.p, lp_col.p, lp_val.p, lp_x.p, lp_lo.p, lp_hi.p, lp_y.p, d_age.p,
              prm.purge_margin, (int)prm.purge_age, d_keep.p, d_keepnnz.p);
+    if (prm.dedupe_eps > 0.0 && lists_ok() && list_count() > 0) {
+        KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
+        LAUNCH_1(k_dedupe_mark, list_count(), stream, list_count(), list_heads(), d_cutprev.p, lp_rowptr.p, lp_val.p, lp_lo.p, lp_hi.p, lp_y.p,
+                 prm.dedupe_eps, d_keep.p, d_keepnnz.p, d_anynf.p + 1);
+        int32_t nd = 0;
+        KTN_HIP(hipMemcpyAsync(&nd, d_anynf.p + 1, 4, hipMemcpyDeviceToHost, stream));
+        sync();
+        stats["deduped_rows"] += (double)nd;
+    }
     check_launch();
     exclusive_scan(d_keep.p, d_newidx.p, (size_t)m);
     exclusive_scan(d_keepnnz.p, d_newptr.p, (size_t)m);
@@ -2180,7 +2189,7 @@ void ktn_default_params(ktn_params* p) {
     p->lp_dense_after = 5000;
     p->cut_cap_factor = 2.0; p->cut_cap_min = 10000;
     p->lp_stag_factor = 100.0;
-    p->lp_ruiz_warm = 0; p->lp_tiled_nnz = 4000000; p->lp_near_check = 7;
+    p->lp_ruiz_warm = 0; p->lp_tiled_nnz = 4000000; p->lp_near_check = 7; p->dedupe_eps = 1e-6;
     p->polish_factor = 1e-3; p->polish_max_var = 32; p->polish_max_iter = 30;
 }
 

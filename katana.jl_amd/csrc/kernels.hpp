@@ -559,6 +559,50 @@ __global__ __launch_bounds__(kBlock) void k_purge_mark(int64_t m_base, int64_t m
     keep[r] = k ? 1 : 0;
     keepnnz[r] = k ? len : 0;
 }
+// Near-duplicate cuts (second half; the reference's TODO at src/model.jl:215).  Close to the
+// optimum successive iterates differ by ~1e-6, so successive tangent cuts of an active NL row are the same inequality up
+// to that order -- rows that cost bytes in every PDHG iteration and are what makes the LP's duals degenerate.  For every NL
+// row the cuts older than its NEWEST one are compared with it after normalising by the largest coefficient: a cut whose
+// coefficients and bound agree within `eps` is dropped (dropping a cut only loosens the outer approximation, by O(eps)
+// here) and its multiplier moves to the newest cut.  One thread per NL slot walks the slot's list (deterministic).
+__global__ __launch_bounds__(kBlock) void k_dedupe_mark(int64_t nslots, const int64_t* __restrict__ last_cut,
+                                                        const int64_t* __restrict__ cut_prev, const int64_t* __restrict__ rowptr,
+                                                        const double* __restrict__ val, const double* __restrict__ lo,
+                                                        const double* __restrict__ hi, double* __restrict__ y, double eps,
+                                                        int64_t* __restrict__ keep, int64_t* __restrict__ keepnnz,
+                                                        int32_t* __restrict__ dropped) {
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= nslots) return;
+    const int64_t head = last_cut[s];
+    if (head < 0 || !keep[head]) return;
+    const int64_t hb = rowptr[head], hl = rowptr[head + 1] - hb;
+    double nh = 0.0;
+    for (int64_t e = 0; e < hl; ++e) nh = fmax(nh, fabs(val[hb + e]));
+    if (!(nh > 0.0) || !isfinite(nh)) return;
+    const bool up = isfinite(hi[head]);                     // a cut has one finite side (src/model.jl:74-75)
+    const double bh = (up ? hi[head] : lo[head]) / nh;
+    if (!isfinite(bh)) return;
+    int nd = 0;
+    for (int64_t r = cut_prev[head]; r >= 0; r = cut_prev[r]) {
+        if (!keep[r]) continue;
+        const int64_t rb = rowptr[r];
+        if (rowptr[r + 1] - rb != hl || isfinite(hi[r]) != up) continue;
+        double nr = 0.0;
+        for (int64_t e = 0; e < hl; ++e) nr = fmax(nr, fabs(val[rb + e]));
+        if (!(nr > 0.0) || !isfinite(nr)) continue;
+        const double br = (up ? hi[r] : lo[r]) / nr;
+        if (!(fabs(br - bh) <= eps * (1.0 + fabs(bh)))) continue;
+        double diff = 0.0;
+        for (int64_t e = 0; e < hl; ++e) diff = fmax(diff, fabs(val[rb + e] / nr - val[hb + e] / nh));
+        if (!(diff <= eps)) continue;
+        keep[r] = 0;
+        keepnnz[r] = 0;
+        y[head] += y[r] * (nr / nh);                        // A'y changes by O(eps |y|)
+        y[r] = 0.0;
+        ++nd;
+    }
+    if (nd) atomicAdd(dropped, nd);
+}
 __global__ __launch_bounds__(kBlock) void k_purge_copy(int64_t m, const int64_t* __restrict__ keep, const int64_t* __restrict__ newidx,
                                                        const int64_t* __restrict__ newptr, LpRows Old, const int32_t* __restrict__ age_old,
                                                        LpRows New, int32_t* __restrict__ age_new) {

@@ -36,6 +36,9 @@ ATOM_LIN, ATOM_QUAD, ATOM_EXP, ATOM_NEGLOG = 0, 1, 2, 3
 # BASELINE.json configs (k = nnz per nonlinear row fixed in SURVEY.md section 8)
 CONFIGS = {
     "cfg2": dict(n=10_000, m_nl=1_000, k=64, family="quad"),
+    # BASELINE.json configs[1] says "convex QP": the same rows under the quadratic objective 1/2 |x - x0|_D^2, which enters
+    # through the (dense) epigraph row f(x) - t <= 0 (src/nlpeval.jl:42-63; SURVEY.md section 8d "cfg2 QP variant")
+    "cfg2_qp": dict(n=10_000, m_nl=1_000, k=64, family="quad", objective="quad"),
     "cfg3": dict(n=100_000, m_nl=10_000, k=32, family="explog"),
     "cfg3_hbm": dict(n=100_000, m_nl=10_000, k=2048, family="explog"),
     "cfg4": dict(n=100_000, m_nl=1_000_000, k=32, family="explog"),

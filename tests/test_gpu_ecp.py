@@ -123,14 +123,14 @@ def test_cut_pool_purging_keeps_the_answer():
     assert max_nl_violation(inst, purge.getsolution()) <= 1e-6 * (1 + 1e-6)
 
 
-@pytest.mark.parametrize("name,seed", [("cfg2", 1), ("cfg2", 2), ("cfg2", 3), ("cfg2", 4), ("cfg3", 1), ("cfg3", 3),
-                                       ("cfg5_one", 2)])
+@pytest.mark.parametrize("name,seed", [("cfg2", 1), ("cfg2", 2), ("cfg2", 3), ("cfg2", 4), ("cfg2_qp", 0), ("cfg2_qp", 1),
+                                       ("cfg3", 1), ("cfg3", 3), ("cfg5_one", 2)])
 def test_full_size_configs_other_seeds(name, seed):
     """BASELINE.json configs at full size, seeds 1-4: planted optimum, feasibility, x"""
     inst = ktn.instances.make_config(name, seed=seed)
     m = hip_load_instance(ktn, inst)
     assert m.optimize() == "Optimal"
-    x = m.getsolution()
+    x = m.getsolution()[:inst.n]
     assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
     assert max_nl_violation(inst, x) <= 1e-6 * (1 + 1e-6)
     assert np.max(np.abs(x - inst.xhat)) <= 1e-3
@@ -247,3 +247,37 @@ def test_full_batch_of_512_cfg5_instances_one_workgroup_per_instance():
     ref, _ = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts[:64], fused=True, per_instance_lp=False)
     for a, b, inst in zip(res[:64], ref, insts[:64]):
         assert abs(a["objval"] - b["objval"]) <= planted_obj_bound(inst)
+
+
+def test_reference_faithful_preset_against_the_oracle():
+    """the reference's own loop -- every violated row cut, no cut ever removed, the LP solved to the full gap criterion
+    (purge_age = 0, cut_cap_factor = 0, lp_stag_factor = 0, dedupe_eps = 0, lp_near_check = 0: src/model.jl:257-309 as
+    written) -- at n = 5000 against the CPU oracle: status, objective within the per-instance bound, feasibility, and the
+    same cumulative cut count up to the rows that sit within 1e-6 of the tolerance on one side only"""
+    inst = ktn.instances.make_instance(n=5000, m_nl=500, k=32, family="explog", seed=7)
+    m = hip_load_instance(ktn, inst, purge_age=0, cut_cap_factor=0.0, lp_stag_factor=0.0, dedupe_eps=0.0, lp_near_check=0)
+    assert m.optimize() == "Optimal"
+    om = oracle_solve_instance(inst)
+    assert om.getstatus() == "Optimal"
+    assert abs(m.getobjval() - om.getobjval()) <= planted_obj_bound(inst)
+    assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
+    assert max_nl_violation(inst, m.getsolution()) <= 1e-6 * (1 + 1e-6)
+    assert m.stat("purged_rows") == 0 and m.stat("cut_selections") == 0 and m.stat("lp_stagnation_exits") == 0
+    assert m.lp_num_rows() == m.numcuts()                                   # nothing was ever removed (src/model.jl:215)
+    assert abs(m.numiters() - om.numiters()) <= 4                           # inexact-LP rule: a re-solve or two more
+
+
+def test_near_duplicate_cuts_are_dropped_without_moving_the_answer():
+    """SURVEY.md section 8f-1 (the reference's TODO, src/model.jl:215): with dedupe_eps the LP at convergence holds fewer
+    rows -- the late, nearly identical cuts of the active rows collapse onto the newest -- and the objective is the same to
+    1e-7 relative"""
+    inst = ktn.instances.make_config("cfg3", seed=0)
+    res = {}
+    for eps in (0.0, 1e-6):
+        m = hip_load_instance(ktn, inst, dedupe_eps=eps)
+        assert m.optimize() == "Optimal"
+        res[eps] = (m.getobjval(), m.lp_num_rows(), m.stat("deduped_rows"), max_nl_violation(inst, m.getsolution()))
+    assert res[0.0][2] == 0 and res[1e-6][2] > 0
+    assert res[1e-6][1] < res[0.0][1]
+    assert abs(res[1e-6][0] - res[0.0][0]) <= 1e-7 * max(1.0, abs(res[0.0][0]))
+    assert res[1e-6][3] <= 1e-6 * (1 + 1e-6)
