@@ -202,6 +202,7 @@ void ktn_default_params(ktn_params* p);
 
 /* KatanaSolver(lp_solver; kwargs) + MathProgBase.NonlinearModel(s)
  * (src/solver.jl:34-43, src/model.jl:41-65) */
+/* (on failure no handle exists, so ktn_last_error cannot be asked: the message goes to stderr, the code is returned) */
 int ktn_create(const ktn_params* p, ktn_handle* out);
 void ktn_destroy(ktn_handle h);
 const char* ktn_last_error(ktn_handle h);

@@ -125,6 +125,21 @@ static inline int pick_group(double avg_len) {
         }                                                                                                \
     } while (0)
 
+// G lanes per output, T outputs per lane group: grid = ceil(count * G / (kBlock * T))
+#define LAUNCH_GT(G, T, KERNEL, count, stream, E0, E1, ...)                                              \
+    do {                                                                                                 \
+        const int64_t cnt__ = (count);                                                                   \
+        if (cnt__ > 0) {                                                                                 \
+            switch (G) {                                                                                 \
+                case 4: hipExtLaunchKernelGGL((KERNEL<4, T>), dim3(ceil_div(cnt__ * 4, kBlock * T)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break;   \
+                case 8: hipExtLaunchKernelGGL((KERNEL<8, T>), dim3(ceil_div(cnt__ * 8, kBlock * T)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break;   \
+                case 16: hipExtLaunchKernelGGL((KERNEL<16, T>), dim3(ceil_div(cnt__ * 16, kBlock * T)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break; \
+                case 32: hipExtLaunchKernelGGL((KERNEL<32, T>), dim3(ceil_div(cnt__ * 32, kBlock * T)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break; \
+                default: hipExtLaunchKernelGGL((KERNEL<64, T>), dim3(ceil_div(cnt__ * 64, kBlock * T)), dim3(kBlock), 0, stream, E0, E1, 0, __VA_ARGS__); break; \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+
 #define LAUNCH_1(KERNEL, count, stream, ...)                                                             \
     do {                                                                                                 \
         const int64_t cnt__ = (count);                                                                   \
@@ -234,6 +249,7 @@ struct Engine {
     DBuf<RowRec> d_rrec;
     DBuf<int2> d_cbl;
     bool packed_on = false;        // plain steps read packed per-column / per-row records (kernels.hpp)
+    int packed_trips = 1;          // outputs per lane group in the packed kernels (KTN_PACKED_TRIPS: 1, 2, 4)
     DBuf<double> dr, dc, statr, statc, ch, lh, uh, loh, hih, xh, yh, x0h, y0h, xth, yth, xbar, pv, pw, box;
     DBuf<double> partials, chk_part, chkout, power_v;
     // exact small-LP path (dense_lp.hpp)
@@ -1411,8 +1427,9 @@ void Engine::launch_y(const SpMat& A, double sigma, double w, double rho, hipEve
                               loh.p, hih.p, sigma, w, rho);
     } else if (packed_on) {
         const int thr32 = n_long > 0 ? (int)kLongRow : 0x7fffffff;
-        if (e0) LAUNCH_G_EV(grp_rows, k_pdhg_y_packed, m, stream, e0, e1, m, A.idx, A.val, xbar.p, yh.p, d_rrec.p, sigma, w, rho, thr32);
-        else LAUNCH_G(grp_rows, k_pdhg_y_packed, m, stream, m, A.idx, A.val, xbar.p, yh.p, d_rrec.p, sigma, w, rho, thr32);
+        if (packed_trips == 2) LAUNCH_GT(grp_rows, 2, k_pdhg_y_packed, m, stream, e0, e1, m, A.idx, A.val, xbar.p, yh.p, d_rrec.p, sigma, w, rho, thr32);
+        else if (packed_trips == 4) LAUNCH_GT(grp_rows, 4, k_pdhg_y_packed, m, stream, e0, e1, m, A.idx, A.val, xbar.p, yh.p, d_rrec.p, sigma, w, rho, thr32);
+        else LAUNCH_GT(grp_rows, 1, k_pdhg_y_packed, m, stream, e0, e1, m, A.idx, A.val, xbar.p, yh.p, d_rrec.p, sigma, w, rho, thr32);
     } else if (e0) {
         LAUNCH_G_EV(grp_rows, k_pdhg_y, m, stream, e0, e1, m, A, xbar.p, yh.p, y0h.p, loh.p, hih.p, sigma, w, rho, thr);
     } else {
@@ -1440,8 +1457,9 @@ void Engine::launch_x(const SpMat& AT, double tau, double w, double rho, bool up
             hipExtLaunchKernelGGL(k_x_epilogue, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, n, tAT.pcnt.p,
                                   tpart.p, xh.p, x0h.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
         } else if (packed_on) {
-            if (e0) LAUNCH_G_EV(grp_cols, k_pdhg_x_packed, n, stream, e0, e1, n, d_cbl.p, AT.idx, AT.val, yh.p, xh.p, xbar.p, d_crec.p, tau, w, rho);
-            else LAUNCH_G(grp_cols, k_pdhg_x_packed, n, stream, n, d_cbl.p, AT.idx, AT.val, yh.p, xh.p, xbar.p, d_crec.p, tau, w, rho);
+            if (packed_trips == 2) LAUNCH_GT(grp_cols, 2, k_pdhg_x_packed, n, stream, e0, e1, n, d_cbl.p, AT.idx, AT.val, yh.p, xh.p, xbar.p, d_crec.p, tau, w, rho);
+            else if (packed_trips == 4) LAUNCH_GT(grp_cols, 4, k_pdhg_x_packed, n, stream, e0, e1, n, d_cbl.p, AT.idx, AT.val, yh.p, xh.p, xbar.p, d_crec.p, tau, w, rho);
+            else LAUNCH_GT(grp_cols, 1, k_pdhg_x_packed, n, stream, e0, e1, n, d_cbl.p, AT.idx, AT.val, yh.p, xh.p, xbar.p, d_crec.p, tau, w, rho);
         } else if (e0) {
             LAUNCH_GB_EV(grp_cols, k_pdhg_x, true, n, stream, e0, e1, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
         } else {
@@ -1693,6 +1711,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     // anchors z0 = z; with the packed records of the plain steps (not for the tiled / row-sharded forms, whose steps are
     // split into SpMV + element-wise kernels)
     packed_on = !tiled_on && !row_sharded() && NNZ < ((int64_t)1 << 31) && std::getenv("KTN_NO_PACKED") == nullptr;
+    if (const char* pt = std::getenv("KTN_PACKED_TRIPS")) packed_trips = std::atoi(pt);
     if (packed_on) {
         d_crec.resize((size_t)n, stream); d_cbl.resize((size_t)n, stream); d_rrec.resize(mm, stream);
         LAUNCH_1(k_pack_cols, n, stream, n, c_ptr.p, ch.p, lh.p, uh.p, xh.p, x0h.p, d_crec.p, d_cbl.p);

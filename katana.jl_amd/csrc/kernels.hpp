@@ -758,44 +758,74 @@ __global__ __launch_bounds__(kBlock) void k_pack_rows(int64_t m, const int64_t* 
     RowRec r; r.lo = lo[i]; r.hi = hi[i]; r.y0 = yv; r.beg = (int32_t)ptr[i]; r.len = (int32_t)(ptr[i + 1] - ptr[i]);
     rec[i] = r;
 }
-template <int G>
+// T outputs per lane group (output g, g + groups, ...): the records and the first entries of all T are requested before any
+// is used, so a wavefront keeps T times the loads in flight and the grid is T times smaller (shorter ramp-up and drain of
+// a ~6 us kernel whose boundary costs ~1.5 us).
+template <int G, int T>
 __global__ __launch_bounds__(kBlock) void k_pdhg_x_packed(int64_t n, const int2* __restrict__ bl, const int32_t* __restrict__ idx,
                                                           const double* __restrict__ val, const double* __restrict__ y,
                                                           double* __restrict__ x, double* __restrict__ xbar,
                                                           const ColRec* __restrict__ rec, double tau, double w, double rho) {
-    const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int64_t groups = (int64_t)gridDim.x * (kBlock / G);
+    const int64_t g0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
-    if (j >= n) return;
-    const int2 b = bl[j];
-    const ColRec r = rec[j];
-    const double xv = x[j];
-    double acc = 0.0;
-    for (int e = b.x + lane; e < b.x + b.y; e += G) acc += val[e] * y[idx[e]];
-    acc = group_sum<G>(acc);
-    if (lane == 0) {
-        const double xtv = clampd(xv - tau * (r.c - acc), r.l, r.u);
-        xbar[j] = 2.0 * xtv - xv;
-        x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * r.x0;
+    int2 b[T];
+    ColRec r[T];
+    double xv[T], acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int64_t j = g0 + t * groups;
+        const bool on = j < n;
+        b[t] = on ? bl[j] : make_int2(0, 0);
+        if (on) r[t] = rec[j];
+        xv[t] = on ? x[j] : 0.0;
+        acc[t] = 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        for (int e = b[t].x + lane; e < b[t].x + b[t].y; e += G) acc[t] += val[e] * y[idx[e]];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int64_t j = g0 + t * groups;
+        const double a = group_sum<G>(acc[t]);
+        if (lane == 0 && j < n) {
+            const double xtv = clampd(xv[t] - tau * (r[t].c - a), r[t].l, r[t].u);
+            xbar[j] = 2.0 * xtv - xv[t];
+            x[j] = w * ((1.0 + rho) * xtv - rho * xv[t]) + (1.0 - w) * r[t].x0;
+        }
     }
 }
-template <int G>
+template <int G, int T>
 __global__ __launch_bounds__(kBlock) void k_pdhg_y_packed(int64_t m, const int32_t* __restrict__ idx, const double* __restrict__ val,
                                                           const double* __restrict__ xbar, double* __restrict__ y,
                                                           const RowRec* __restrict__ rec, double sigma, double w, double rho,
                                                           int long_thresh) {
-    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int64_t groups = (int64_t)gridDim.x * (kBlock / G);
+    const int64_t g0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
-    if (i >= m) return;
-    const RowRec r = rec[i];
-    if (r.len > long_thresh) return;              // served by k_pdhg_y_long (a workgroup per row)
-    const double yv = y[i];
-    double acc = 0.0;
-    for (int e = r.beg + lane; e < r.beg + r.len; e += G) acc += val[e] * xbar[idx[e]];
-    acc = group_sum<G>(acc);
-    if (lane == 0) {
-        const double v = yv - sigma * acc;
-        const double ytv = v + sigma * clampd(-v / sigma, r.lo, r.hi);
-        y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * r.y0;
+    RowRec r[T];
+    double yv[T], acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int64_t i = g0 + t * groups;
+        const bool on = i < m;
+        if (on) r[t] = rec[i]; else { r[t].beg = 0; r[t].len = 0; }
+        if (r[t].len > long_thresh) r[t].len = -1;      // served by k_pdhg_y_long (a workgroup per row)
+        yv[t] = on ? y[i] : 0.0;
+        acc[t] = 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        for (int e = r[t].beg + lane; e < r[t].beg + r[t].len; e += G) acc[t] += val[e] * xbar[idx[e]];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int64_t i = g0 + t * groups;
+        const double a = group_sum<G>(acc[t]);
+        if (lane == 0 && i < m && r[t].len >= 0) {
+            const double v = yv[t] - sigma * a;
+            const double ytv = v + sigma * clampd(-v / sigma, r[t].lo, r[t].hi);
+            y[i] = w * ((1.0 + rho) * ytv - rho * yv[t]) + (1.0 - w) * r[t].y0;
+        }
     }
 }
 
