@@ -324,6 +324,14 @@ int ktn_lp_append_rows(ktn_handle h, int64_t nrows, const int64_t* rowptr, const
  * (iterates in LDS, __syncthreads() instead of kernel boundaries, restarts and termination decided per instance), while
  * the sweep and the cut bookkeeping keep serving the whole batch at once.  nblocks = 0 switches it off. */
 int ktn_set_blocks(ktn_handle h, int64_t nblocks, const int64_t* col_offsets);
+/* MathProgBase.optimize! for such a batch with the WHOLE loop of src/model.jl:257-309 of every instance inside its own
+ * workgroup (csrc/batch_ecp.hpp): LP scaling, step-size estimate, PDHG with its checks and restarts, the sweep over the
+ * instance's NL rows, cut append, column mirror, tolerance schedule and stop rule -- no instance waits for another.  Needs
+ * separable rows, a linear :Min objective, finite variable bounds and the instances' rows grouped instance after instance
+ * (instances.fuse_instances); `cut_capacity` = room for that many cuts per NL row (<= 0: 12).  Falls back to the ordinary
+ * loop when the batch does not qualify or an instance runs out of room.  Returns the status like ktn_optimize; getters as usual
+ * (numiters = the largest per-instance count, numcuts = the sum). */
+int ktn_optimize_blocks(ktn_handle h, int32_t cut_capacity);
 
 /* ---- row-sharded LP over several GPUs (no reference counterpart: it splits the LP re-solve of
  * src/model.jl:259 and the cut loop of :272-283 over the ranks) -------------------------------------------------------

@@ -97,6 +97,7 @@ PROTOTYPES = {
     "ktn_last_sweep_slots": (c_i32, [C.c_void_p, P(c_i64), c_i64, P(c_i64)]),
     "ktn_lp_append_rows_nl": (c_i32, [C.c_void_p, c_i64, P(c_i64), P(c_i32), P(c_f64), P(c_f64), P(c_f64), P(c_i64)]),
     "ktn_set_blocks": (c_i32, [C.c_void_p, c_i64, P(c_i64)]),
+    "ktn_optimize_blocks": (c_i32, [C.c_void_p, c_i32]),
     "ktn_dist_unique_id": (c_i32, [C.c_char_p]),
     "ktn_dist_init_rccl": (c_i32, [C.c_void_p, C.c_char_p, c_i32, c_i32]),
     "ktn_dist_init_callback": (c_i32, [C.c_void_p, c_i32, c_i32, C.c_void_p, C.c_void_p]),

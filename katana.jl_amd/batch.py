@@ -12,7 +12,7 @@ from .nlp import SeparableNLP
 from .solver import NonlinearModel
 
 
-def solve_batch(solver, instances, threads=16, describe=SeparableNLP, fused=False, per_instance_lp=False):
+def solve_batch(solver, instances, threads=16, describe=SeparableNLP, fused=False, per_instance_lp=False, device_loop=None):
     """Solve every instance; returns (results, wall_seconds).  results[i] = dict(status, objval, iters,
     numcuts, x) in the order of `instances`.
 
@@ -23,9 +23,14 @@ def solve_batch(solver, instances, threads=16, describe=SeparableNLP, fused=Fals
     With per_instance_lp every LP re-solve of the fused problem is ONE launch with one workgroup per instance
     (ktn_set_blocks, csrc/batch_lp.hpp: iterates in LDS, restarts and termination per instance) instead of the global
     first-order loop.  Measured on 512 x cfg5: 2.5x fewer instance-iterations in total, but every
-    cutting-plane round still waits for its slowest instance, so the batch takes 0.26 s against 0.22 s -- hence off by default."""
+    cutting-plane round still waits for its slowest instance, so the batch takes 0.26 s against 0.22 s -- hence off by default.
+    With device_loop (the default for fused batches) the WHOLE cutting-plane loop of every instance runs inside its own
+    workgroup (ktn_optimize_blocks, csrc/batch_ecp.hpp): no instance waits for another; 0.10 s for 512 x cfg5.  Batches it does
+    not cover (tape rows, nonlinear objective, free variables) fall back to the host-driven loop inside the call."""
+    if device_loop is None:
+        device_loop = fused and not per_instance_lp
     if fused:
-        return _solve_fused(solver, instances, per_instance_lp)
+        return _solve_fused(solver, instances, per_instance_lp, device_loop)
     def work(inst):
         m = NonlinearModel(solver)
         m.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense,
@@ -43,16 +48,16 @@ def solve_batch(solver, instances, threads=16, describe=SeparableNLP, fused=Fals
     return out, time.perf_counter() - t0
 
 
-def _solve_fused(solver, instances, per_instance_lp=False):
+def _solve_fused(solver, instances, per_instance_lp=False, device_loop=False):
     import numpy as np
     from .instances import atom_value_deriv, fuse_instances
     t0 = time.perf_counter()
     big, offs = fuse_instances(instances)
     m = NonlinearModel(solver)
     m.loadproblem(big.n, big.num_constr, big.l_var, big.u_var, big.l_constr, big.u_constr, big.sense, SeparableNLP(big))
-    if per_instance_lp:
+    if per_instance_lp or device_loop:
         m.set_blocks(offs)
-    status = m.optimize()
+    status = m.optimize_blocks() if device_loop else m.optimize()
     x = m.getsolution()
     out = []
     for k, inst in enumerate(instances):
@@ -61,5 +66,7 @@ def _solve_fused(solver, instances, per_instance_lp=False):
                                   xi[np.asarray(inst.obj_col)])
         out.append(dict(status=status, objval=float(val.sum() + inst.obj_const), iters=m.numiters(), numcuts=None, x=xi,
                         pdhg_iters=m.stat("pdhg_iters"), blk_lp_launches=m.stat("blk_lp_launches"),
-                        blk_lp_fallbacks=m.stat("blk_lp_fallbacks"), blk_pdhg_iters_sum=m.stat("blk_pdhg_iters_sum")))
+                        blk_lp_fallbacks=m.stat("blk_lp_fallbacks"), blk_pdhg_iters_sum=m.stat("blk_pdhg_iters_sum"),
+                        ecp_blocks_launches=m.stat("ecp_blocks_launches"), ecp_blocks_fallbacks=m.stat("ecp_blocks_fallbacks"),
+                        ecp_blocks_pdhg_sum=m.stat("ecp_blocks_pdhg_sum")))
     return out, time.perf_counter() - t0

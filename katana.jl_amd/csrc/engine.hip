@@ -28,6 +28,7 @@
 #include "kernels.hpp"
 #include "dense_lp.hpp"
 #include "batch_lp.hpp"
+#include "batch_ecp.hpp"
 #include "prims.hpp"
 
 namespace ktn {
@@ -288,6 +289,11 @@ struct Engine {
     DBuf<double> d_blkomega, d_blkres;
     int blk_nmax = 0, blk_mmax = 0;
     void build_blocks();
+    bool optimize_blocks_device(int cap_mul);
+    DBuf<EcpArena> d_ar;                          // arenas of the device-side loop
+    DBuf<int64_t> d_blklin, d_blknl;
+    DBuf<int32_t> e_rptr, e_rcol, e_cptr, e_crow, e_last, e_prev;
+    DBuf<double> e_ax, e_rval, e_rsval, e_lo, e_hi, e_y, e_dr, e_loh, e_hih, e_cval, e_csval, e_dc, e_ch, e_lh, e_uh, e_res;     // batch_ecp.hpp: the whole ECP loop of every instance in its own workgroup
     bool lp_solve_blocks(double tol_p, double tol_g, double eta, LpResult* R, int64_t max_it);
     double smax_prev = 0.0;
     int64_t smax_rows = 0;
@@ -1391,6 +1397,124 @@ bool Engine::lp_solve_blocks(double tol_p, double tol_g, double eta, LpResult* R
     return true;
 }
 
+// Throughput mode, device-side loop (batch_ecp.hpp).  Returns false when the problem does not qualify or an instance
+// could not finish (arena overflow, LP status): the caller then runs the ordinary loop.
+bool Engine::optimize_blocks_device(int cap_mul) {
+    if (n_blocks <= 0 || !obj_linear || sense != KTN_MIN || has_inf_bound || n_tape_nl > 0 || n_host > 0 || prm.vis_data) return false;
+    for (int64_t i = 0; i < m_ext - 1; ++i) if (h_rowkind[(size_t)i] != KTN_ROW_SEP) return false;
+    const int nb = (int)n_blocks;
+    auto block_of_col = [&](int64_t c) { return (int)(std::upper_bound(h_blkcol.begin(), h_blkcol.end(), c) - h_blkcol.begin()) - 1; };
+    // linear rows of the loaded LP (in original row order) and NL slots must be grouped by instance, instance after instance
+    std::vector<int64_t> lin_rows, blk_lin((size_t)nb + 1, 0), blk_nl((size_t)nb + 1, 0), nnz_lin((size_t)nb, 0), nnz_nl((size_t)nb, 0);
+    {
+        std::vector<char> is_nl((size_t)m0, 0);
+        for (auto r : h_nlrows) if (r < m0) is_nl[(size_t)r] = 1;
+        for (int64_t i = 0; i < m0; ++i) if (!is_nl[(size_t)i]) lin_rows.push_back(i);
+    }
+    if ((int64_t)lin_rows.size() != M_base) return false;
+    int prev = 0;
+    for (size_t k = 0; k < lin_rows.size(); ++k) {
+        const int64_t r = lin_rows[k];
+        if (h_rowptr[r + 1] == h_rowptr[r]) return false;
+        const int bb = block_of_col(h_col[(size_t)h_rowptr[r]]);
+        if (bb < prev || bb >= nb) return false;
+        for (int64_t e = h_rowptr[r]; e < h_rowptr[r + 1]; ++e) if (block_of_col(h_col[(size_t)e]) != bb) return false;
+        prev = bb;
+        blk_lin[(size_t)bb + 1] += 1;
+        nnz_lin[(size_t)bb] += h_rowptr[r + 1] - h_rowptr[r];
+    }
+    prev = 0;
+    for (size_t k = 0; k < h_nlrows.size(); ++k) {
+        const int64_t r = h_nlrows[k];
+        if (h_rowptr[r + 1] == h_rowptr[r]) return false;
+        const int bb = block_of_col(h_col[(size_t)h_rowptr[r]]);
+        if (bb < prev || bb >= nb) return false;
+        for (int64_t e = h_rowptr[r]; e < h_rowptr[r + 1]; ++e) if (block_of_col(h_col[(size_t)e]) != bb) return false;
+        prev = bb;
+        blk_nl[(size_t)bb + 1] += 1;
+        nnz_nl[(size_t)bb] += h_rowptr[r + 1] - h_rowptr[r];
+    }
+    for (int bb = 0; bb < nb; ++bb) { blk_lin[(size_t)bb + 1] += blk_lin[(size_t)bb]; blk_nl[(size_t)bb + 1] += blk_nl[(size_t)bb]; }
+    // arenas
+    std::vector<EcpArena> ar((size_t)nb);
+    int64_t row_tot = 0, nnz_tot = 0;
+    int mmax = 1;
+    for (int bb = 0; bb < nb; ++bb) {
+        const int64_t ml = blk_lin[(size_t)bb + 1] - blk_lin[(size_t)bb], mn = blk_nl[(size_t)bb + 1] - blk_nl[(size_t)bb];
+        EcpArena a;
+        a.row0 = row_tot; a.nnz0 = nnz_tot;
+        a.cap_rows = (int32_t)(ml + (int64_t)cap_mul * mn);
+        a.cap_nnz = (int32_t)(nnz_lin[(size_t)bb] + (int64_t)cap_mul * nnz_nl[(size_t)bb]);
+        row_tot += a.cap_rows; nnz_tot += a.cap_nnz;
+        mmax = std::max<int>(mmax, std::max<int>(a.cap_rows, (int)mn));
+        ar[(size_t)bb] = a;
+    }
+    const size_t lds = (size_t)(3 * blk_nmax + 3 * mmax + (kEcpThreads / 64) * kEcpQ + kEcpQ + 8 + 16) * sizeof(double) +
+                       (size_t)(std::max(blk_nmax, mmax) + 4) * sizeof(int32_t);
+    if (lds > 158 * 1024) return false;
+    t_start = std::chrono::steady_clock::now();
+    d_ar.upload(ar, stream); d_blklin.upload(blk_lin, stream); d_blknl.upload(blk_nl, stream);
+    e_rptr.resize((size_t)row_tot + nb + 1, stream);
+    e_rcol.resize((size_t)nnz_tot + 1, stream); e_rval.resize((size_t)nnz_tot + 1, stream); e_rsval.resize((size_t)nnz_tot + 1, stream);
+    e_crow.resize((size_t)nnz_tot + 1, stream); e_cval.resize((size_t)nnz_tot + 1, stream); e_csval.resize((size_t)nnz_tot + 1, stream);
+    for (DBuf<double>* v : {&e_lo, &e_hi, &e_y, &e_dr, &e_loh, &e_hih}) v->resize((size_t)row_tot + 1, stream);
+    e_cptr.resize((size_t)n_lp + nb + 1, stream);
+    for (DBuf<double>* v : {&e_dc, &e_ch, &e_lh, &e_uh}) v->resize((size_t)n_lp + 1, stream);
+    e_last.resize((size_t)std::max<int64_t>(m_nl, 1), stream);
+    e_prev.resize((size_t)row_tot + 1, stream); e_ax.resize((size_t)row_tot + 1, stream);
+    e_res.resize((size_t)nb * 8, stream);
+    EcpBatch B;
+    B.blk_col = d_blkcol.p; B.blk_lin = d_blklin.p; B.blk_nl = d_blknl.p;
+    B.lp_rowptr = lp_rowptr.p; B.lp_col = lp_col.p; B.lp_val = lp_val.p; B.lp_lo = lp_lo.p; B.lp_hi = lp_hi.p;
+    B.c = lp_c.p; B.l = lp_l.p; B.u = lp_u.p;
+    B.P = nlp_view(); B.nl_rows = d_nlrows.p;
+    B.arena = d_ar.p;
+    B.rptr = e_rptr.p; B.rcol = e_rcol.p; B.rval = e_rval.p; B.rsval = e_rsval.p; B.lo = e_lo.p; B.hi = e_hi.p; B.y = e_y.p; B.dr = e_dr.p;
+    B.loh = e_loh.p; B.hih = e_hih.p;
+    B.cptr = e_cptr.p; B.crow = e_crow.p; B.cval = e_cval.p; B.csval = e_csval.p;
+    B.dc = e_dc.p; B.ch = e_ch.p; B.lh = e_lh.p; B.uh = e_uh.p;
+    B.last_cut = e_last.p; B.cut_prev = e_prev.p; B.ax = e_ax.p; B.x = lp_x.p; B.res = e_res.p;
+    B.f_tol = prm.f_tol; B.cut_coef_rng = prm.cut_coef_rng; B.tol_scale = prm.lp_tol_scale; B.tol_floor = prm.lp_tol_floor;
+    B.tol_cap = prm.lp_tol_cap; B.gap_floor = prm.lp_gap_floor; B.gap_cap = prm.lp_gap_cap; B.stag_factor = prm.lp_stag_factor;
+    B.iter_cap = prm.iter_cap; B.lp_max_iter = prm.lp_max_iter; B.check_every = std::max(2, prm.lp_check_every);
+    // (a lone workgroup's check is cheap and every instance stops on its own: a period of 24 halves the iterations of the
+    //  slowest instance against 64 -- 512 x cfg5: max 15 842 -> 5 008, the launch 0.131 -> 0.097 s)
+    B.check_every = std::min(B.check_every, 24);
+    B.near_chunk = prm.lp_near_check; B.ruiz_iters = prm.lp_ruiz_iters; B.nmax = blk_nmax; B.mmax = mmax;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        KTN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ecp_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    // the loaded state: M == M_base rows (the linear rows), as after reset()
+    hipLaunchKernelGGL(k_ecp_blocks, dim3((unsigned)nb), dim3(kEcpThreads), lds, stream, B);
+    check_launch();
+    std::vector<double> res = e_res.to_host(stream);
+    bool ok = true;
+    double obj = 0.0, it_max = 0.0, cuts = 0.0, pd = 0.0, rows = 0.0;
+    for (int bb = 0; bb < nb; ++bb) {
+        const double* o = res.data() + (size_t)bb * 8;
+        if ((int)o[0] != KTN_STATUS_OPTIMAL) ok = false;
+        obj += o[2]; it_max = std::max(it_max, o[1]); cuts += o[3]; pd += o[4]; rows += o[6];
+    }
+    if (std::getenv("KTN_DEBUG_BLOCKS")) {
+        std::vector<std::pair<double, int>> v;
+        for (int bb = 0; bb < nb; ++bb) v.push_back({res[(size_t)bb * 8 + 4], bb});
+        std::sort(v.begin(), v.end());
+        std::fprintf(stderr, "[ecp blocks] pdhg per instance: min %.0f median %.0f p90 %.0f p99 %.0f max %.0f (instance %d, %g ecp iterations, %g rows)\n",
+                     v.front().first, v[v.size() / 2].first, v[v.size() * 9 / 10].first, v[v.size() * 99 / 100].first, v.back().first, v.back().second,
+                     res[(size_t)v.back().second * 8 + 1], res[(size_t)v.back().second * 8 + 6]);
+    }
+    stats["ecp_blocks_launches"] += 1.0;
+    stats["ecp_blocks_pdhg_sum"] += pd;
+    stats["ecp_blocks_rows"] = rows;
+    if (!ok) { stats["ecp_blocks_fallbacks"] += 1.0; return false; }
+    status = KTN_STATUS_OPTIMAL; lp_status = KTN_STATUS_OPTIMAL;
+    iter = (int64_t)it_max; numcuts = (int64_t)cuts; objval = obj + c0; allsat = true;
+    soltime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    return true;
+}
+
 void Engine::find_long_rows() {
     n_long = 0;
     if (M == 0) return;
@@ -1829,7 +1953,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         }
         // primal infeasibility: yt is a Farkas certificate when the dual objective of the c = 0 problem is
         // positive (weak duality makes it <= 0 for every sign-valid y of a feasible LP).  Two checks in a row.
-        if (mode == 0 && m > 0) {
+        if (mode == 0 && (m > 0 || row_sharded())) {     // (row-sharded: every quantity below is all-reduced, so all ranks agree)
             const double farkas = dobj_rows + q[kChkQ + 10];
             const double mag = q[10] + q[kChkQ + 11] + 1e-300;
             const bool cert = farkas > 1e-6 * mag && q[kChkQ + 14] <= 1e-9 * (1.0 + std::sqrt(yt2)) && pviol > tol_p;
@@ -1855,7 +1979,11 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         // objective converged, rows not, residual flat: PDHG is idling between near-parallel cuts of one
         // NL row (k_consolidate).  Move the multiplier mass onto the tightest cut at the current point and
         // restart from there.
-        if (mode == 0 && k > 0 && prm.lp_dual_inherit && lists_ok() && list_count() > 0 && m > M_base && gap <= tol_g &&
+        // (row-sharded: the decision must not depend on what THIS rank holds -- a rank that consolidated while another did not
+        //  would leave the sequence of collectives -- so the local conditions are dropped; k_consolidate on a rank without cuts
+        //  is a no-op)
+        const bool have_lists = row_sharded() ? (prm.lp_dual_inherit != 0) : (prm.lp_dual_inherit && lists_ok() && list_count() > 0 && m > M_base);
+        if (mode == 0 && k > 0 && have_lists && gap <= tol_g &&
             dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2)) && pviol > tol_p) {
             flat_rows = (r_last_check > 0.0 && r > 0.98 * r_last_check) ? flat_rows + 1 : 0;
             if (flat_rows >= 3 && consolidations < 8) {
@@ -2562,6 +2690,22 @@ int ktn_set_blocks(ktn_handle h, int64_t nblocks, const int64_t* col_offsets) {
         e->n_blocks = nblocks;
         e->blocks_built_rows = -1;
         return KTN_OK;
+    })
+}
+
+int ktn_optimize_blocks(ktn_handle h, int32_t cut_capacity) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && e->n_blocks > 0, "ktn_optimize_blocks: after ktn_loadproblem and ktn_set_blocks");
+        if (e->M != e->M_base || e->iter != 0) e->reset();
+        if (e->optimize_blocks_device(cut_capacity > 0 ? cut_capacity : 12)) return e->status;
+        // an instance did not finish on the device (or the problem does not qualify): the ordinary loop, from the loaded state
+        e->reset();
+        e->begin();
+        int32_t done = (e->status == KTN_STATUS_ERROR || e->status == KTN_STATUS_UNBOUNDED) ? 1 : 0;
+        while (!done) e->step(&done);
+        e->end();
+        return e->status;
     })
 }
 

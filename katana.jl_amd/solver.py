@@ -142,6 +142,10 @@ class KatanaNonlinearModel:
         off = np.ascontiguousarray(col_offsets, dtype=np.int64)
         L.check(self._h, self._lib.ktn_set_blocks(self._h, len(off) - 1, _p(off, C.c_int64)))
 
+    def optimize_blocks(self, cut_capacity=0):
+        """optimize! of a block-diagonal batch with every instance's whole loop in its own workgroup (ktn_optimize_blocks)"""
+        return STATUS_SYMBOLS[L.check(self._h, self._lib.ktn_optimize_blocks(self._h, int(cut_capacity)))]
+
     def stat(self, name):
         return float(self._lib.ktn_get_stat(self._h, name.encode()))
 

@@ -244,7 +244,7 @@ def test_full_batch_of_512_cfg5_instances_one_workgroup_per_instance():
         assert max_nl_violation(inst, r["x"]) <= 1e-6 * (1 + 1e-6)
         assert np.max(np.abs(r["x"] - inst.xhat)) <= 1e-3
     # the same batch through the global first-order loop: the same answers up to the stop rule
-    ref, _ = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts[:64], fused=True, per_instance_lp=False)
+    ref, _ = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts[:64], fused=True, per_instance_lp=False, device_loop=False)
     for a, b, inst in zip(res[:64], ref, insts[:64]):
         assert abs(a["objval"] - b["objval"]) <= planted_obj_bound(inst)
 
@@ -281,3 +281,30 @@ def test_near_duplicate_cuts_are_dropped_without_moving_the_answer():
     assert res[1e-6][1] < res[0.0][1]
     assert abs(res[1e-6][0] - res[0.0][0]) <= 1e-7 * max(1.0, abs(res[0.0][0]))
     assert res[1e-6][3] <= 1e-6 * (1 + 1e-6)
+
+
+def test_device_side_loop_one_workgroup_per_instance_small_batch():
+    """ktn_optimize_blocks (csrc/batch_ecp.hpp): the whole cutting-plane loop of every instance inside its own workgroup;
+    each instance ends at its planted optimum within f_tol, like the host-driven fused batch"""
+    insts = [ktn.instances.make_instance(n=300, m_nl=30, k=8, family="explog", seed=300 + s) for s in range(16)]
+    res, _ = ktn.solve_batch(ktn.KatanaSolver(log_level=0, lp_max_iter=400000), insts, fused=True, device_loop=True)
+    assert res[0]["ecp_blocks_launches"] == 1 and res[0]["ecp_blocks_fallbacks"] == 0
+    ref, _ = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts, fused=True, device_loop=False)
+    for r, f, inst in zip(res, ref, insts):
+        assert r["status"] == "Optimal"
+        assert abs(r["objval"] - inst.opt_obj) <= planted_obj_bound(inst)
+        assert abs(r["objval"] - f["objval"]) <= planted_obj_bound(inst)
+        assert max_nl_violation(inst, r["x"]) <= 1e-6 * (1 + 1e-6)
+        assert np.max(np.abs(r["x"] - inst.xhat)) <= 1e-3
+
+
+def test_device_side_loop_full_batch_of_512_cfg5():
+    """BASELINE.json configs[4] at full size through the device-side loop"""
+    insts = [ktn.instances.make_config("cfg5_one", seed=s) for s in range(512)]
+    res, wall = ktn.solve_batch(ktn.KatanaSolver(log_level=0, lp_max_iter=400000), insts, fused=True, device_loop=True)
+    assert len(res) == 512 and res[0]["ecp_blocks_launches"] == 1 and res[0]["ecp_blocks_fallbacks"] == 0
+    for r, inst in zip(res, insts):
+        assert r["status"] == "Optimal"
+        assert abs(r["objval"] - inst.opt_obj) <= planted_obj_bound(inst)
+        assert max_nl_violation(inst, r["x"]) <= 1e-6 * (1 + 1e-6)
+        assert np.max(np.abs(r["x"] - inst.xhat)) <= 1e-3

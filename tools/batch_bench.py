@@ -12,11 +12,13 @@ for thr in [int(a) for a in sys.argv[2:]] or [1, 8, 32]:
     print(json.dumps({"threads": thr, "instances": len(res), "optimal": ok, "wall_s": wall, "instances_per_s": len(res) / wall,
                       "max_obj_relerr": err, "ecp_iters_mean": sum(r["iters"] for r in res) / len(res)}), flush=True)
 
-for per_inst in (True, False, True):
-    res, wall = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts, fused=True, per_instance_lp=per_inst)
+for mode in ("device_loop", "global_lp", "per_instance_lp", "device_loop"):
+    kw = dict(device_loop=(mode == "device_loop"), per_instance_lp=(mode == "per_instance_lp"))
+    res, wall = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts, fused=True, **kw)
     ok = sum(r["status"] == "Optimal" for r in res)
     err = max(abs(r["objval"] - i.opt_obj) / max(1, abs(i.opt_obj)) for r, i in zip(res, insts))
-    print(json.dumps({"fused": True, "per_instance_lp": per_inst, "instances": len(res), "optimal": ok, "wall_s_incl_load": wall,
+    print(json.dumps({"fused": True, "mode": mode, "instances": len(res), "optimal": ok, "wall_s_incl_load": wall,
                       "instances_per_s": len(res) / wall, "max_obj_relerr": err, "ecp_iters": res[0]["iters"],
                       "pdhg_iters": res[0]["pdhg_iters"], "blk_lp_launches": res[0]["blk_lp_launches"],
-                      "blk_lp_fallbacks": res[0]["blk_lp_fallbacks"], "blk_pdhg_iters_sum": res[0]["blk_pdhg_iters_sum"]}), flush=True)
+                      "ecp_blocks_launches": res[0]["ecp_blocks_launches"], "ecp_blocks_fallbacks": res[0]["ecp_blocks_fallbacks"],
+                      "ecp_blocks_pdhg_sum": res[0]["ecp_blocks_pdhg_sum"]}), flush=True)
