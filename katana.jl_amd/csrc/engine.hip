@@ -749,6 +749,15 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     KTN_REQUIRE(num_var >= 0 && num_constr >= 0, "negative sizes");
     KTN_REQUIRE(d->num_var == num_var && d->num_constr == num_constr, "nlp description sizes disagree with loadproblem");
     KTN_REQUIRE(num_var + 1 < ((int64_t)1 << kKindShift), "num_var too large for the packed 29-bit column index");
+    static const bool dbg_load = std::getenv("KTN_DEBUG_LOAD") != nullptr;
+    auto tl0 = std::chrono::steady_clock::now();
+    auto lapl = [&](const char* what) {
+        if (!dbg_load) return;
+        (void)hipStreamSynchronize(stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[load] %-28s %.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - tl0).count());
+        tl0 = now;
+    };
     loaded = false;
     n0 = num_var; m0 = num_constr; sense = sense_;
     obj_linear = d->obj_linear != 0;
@@ -760,14 +769,17 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     //       the reference's dense zeros are remembered in pad_zero for round_coefs)
     h_rowptr.assign(d->rowptr, d->rowptr + m0 + 1);
     h_col.assign(d->col, d->col + nnz0);
-    std::vector<uint8_t> akind(nnz0), padzero(m_ext, 0);
-    std::vector<double> p0(nnz0), p1(nnz0), rconst(m_ext, 0.0);
+    // (bulk copies: a batch of 512 instances brings 3e6 entries through here)
+    std::vector<uint8_t> akind, padzero(m_ext, 0);
+    std::vector<double> p0, p1, rconst(m_ext, 0.0);
+    if (d->atom_kind) akind.assign(d->atom_kind, d->atom_kind + nnz0); else akind.assign((size_t)nnz0, 0);
+    if (d->p0) p0.assign(d->p0, d->p0 + nnz0); else p0.assign((size_t)nnz0, 0.0);
+    if (d->p1) p1.assign(d->p1, d->p1 + nnz0); else p1.assign((size_t)nnz0, 0.0);
     h_rowkind.assign(m_ext, KTN_ROW_SEP);
-    for (int64_t e = 0; e < nnz0; ++e) {
-        akind[e] = d->atom_kind ? d->atom_kind[e] : 0;
-        p0[e] = d->p0 ? d->p0[e] : 0.0;
-        p1[e] = d->p1 ? d->p1[e] : 0.0;
-        KTN_REQUIRE(h_col[e] >= 0 && h_col[e] < n0, "column index out of range");
+    {
+        int32_t cmin = 0, cmax = -1;
+        for (int64_t e = 0; e < nnz0; ++e) { const int32_t c = h_col[e]; cmin = std::min(cmin, c); cmax = std::max(cmax, c); }
+        KTN_REQUIRE(cmin >= 0 && cmax < n0, "column index out of range");
     }
     for (int64_t i = 0; i < m0; ++i) {
         h_rowkind[i] = d->row_kind ? d->row_kind[i] : KTN_ROW_SEP;
@@ -813,6 +825,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     nnz_ext = (int64_t)h_col.size();
     padzero[m0] = (h_rowptr[m0 + 1] - h_rowptr[m0]) < (n0 + 1) ? 1 : 0;
 
+    lapl("extended structure (host)");
     // ---- host-evaluated rows
     cb_rows = d->eval_rows; cb_obj = d->eval_obj; cb_user = d->eval_user;
     host_obj = h_rowkind[m0] == KTN_ROW_HOST;
@@ -884,6 +897,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     for (int64_t j = 0; j < n_lp; ++j)
         if (!std::isfinite(lv[j]) || !std::isfinite(uv[j])) has_inf_bound = true;
 
+    lapl("tapes, bounds, nl list");
     // ---- upload the NLP
     d_rowptr.upload(h_rowptr, stream); d_col.upload(h_col, stream);
     {
@@ -920,6 +934,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     d_nlrows.upload(h_nlrows, stream);
     grp_sweep = pick_group(m_nl ? (double)nnz_nl / (double)m_nl : 4.0);
     if (grp_sweep < 8) grp_sweep = 8;
+    lapl("pack + upload NLP");
     // Long rows (hundreds of entries or more): block-major copy for the column-blocked sweep.  Needs every separable
     // NL row sorted by column (the segments are found by binary search).
     {
@@ -1004,6 +1019,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     d_xs.resize((size_t)n0 + 1, stream); d_ray.resize((size_t)n0 + 1, stream);
     d_flag.zero(stream); d_cnt.zero(stream);
 
+    lapl("blocked copy + sweep buffers");
     // ---- tangent at the origin: linear rows and (linear) objective  model.jl:110-133
     d_xs.zero(stream);
     precompute_all(d_xs.p);
@@ -1012,18 +1028,27 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     std::vector<int32_t> rc;
     std::vector<double> rv, rlo, rhi;
     numcuts = 0;
-    for (auto i : lin_rows) {
-        double b = g0[i];
-        for (int64_t e = h_rowptr[i]; e < h_rowptr[i + 1]; ++e) {
-            rc.push_back(h_col[e]);
-            rv.push_back(j0[e]);
-            b += -0.0 * j0[e];
+    {
+        int64_t tot = 0;
+        for (auto i : lin_rows) tot += h_rowptr[i + 1] - h_rowptr[i];
+        rc.resize((size_t)tot); rv.resize((size_t)tot);
+        rp.reserve(lin_rows.size() + 2); rlo.reserve(lin_rows.size() + 1); rhi.reserve(lin_rows.size() + 1);
+        int64_t pos = 0;
+        for (auto i : lin_rows) {
+            // the tangent at the origin: b = g(0) - sum 0 * J = g(0) (the products vanish unless a coefficient is non-finite)
+            const int64_t beg = h_rowptr[i], len = h_rowptr[i + 1] - beg;
+            std::copy(h_col.begin() + beg, h_col.begin() + beg + len, rc.begin() + pos);
+            std::copy(j0.begin() + beg, j0.begin() + beg + len, rv.begin() + pos);
+            double b = g0[i];
+            for (int64_t e = beg; e < beg + len; ++e) b += -0.0 * j0[e];
+            pos += len;
+            rp.push_back(pos);
+            rlo.push_back(l_constr[i] - b);
+            rhi.push_back(u_constr[i] - b);
+            numcuts += 1;                               // model.jl:77
         }
-        rp.push_back((int64_t)rc.size());
-        rlo.push_back(l_constr[i] - b);
-        rhi.push_back(u_constr[i] - b);
-        numcuts += 1;                                   // model.jl:77
     }
+    lapl("tangent at origin + LP rows (host)");
     std::vector<double> cvec(n_lp, 0.0);
     c0 = 0.0;
     if (prm.log_level > 0) { std::printf(obj_linear ? "objective is linear\n" : "objective is nonlinear\n"); std::fflush(stdout); }   // model.jl:127,135
@@ -1083,6 +1108,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
             }
         }
     }
+    lapl("objective");
     // ---- LP upload
     M = (int64_t)rlo.size();
     NNZ = (int64_t)rc.size();
@@ -1104,9 +1130,11 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
         d_violslots.reserve((size_t)std::max<int64_t>(m_nl, 1), stream);
     }
     sync();
+    lapl("LP upload + reserve");
     loaded = true;
     const int keep_status = status;
     reset();
+    lapl("reset");
     if (keep_status == KTN_STATUS_ERROR) status = KTN_STATUS_ERROR;
 }
 
