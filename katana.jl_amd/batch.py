@@ -59,14 +59,15 @@ def _solve_fused(solver, instances, per_instance_lp=False, device_loop=False):
         m.set_blocks(offs)
     status = m.optimize_blocks() if device_loop else m.optimize()
     x = m.getsolution()
-    out = []
-    for k, inst in enumerate(instances):
-        xi = x[offs[k]:offs[k + 1]]
-        val, _ = atom_value_deriv(np.asarray(inst.obj_kind), np.asarray(inst.obj_p0), np.asarray(inst.obj_p1),
-                                  xi[np.asarray(inst.obj_col)])
-        out.append(dict(status=status, objval=float(val.sum() + inst.obj_const), iters=m.numiters(), numcuts=None, x=xi,
-                        pdhg_iters=m.stat("pdhg_iters"), blk_lp_launches=m.stat("blk_lp_launches"),
-                        blk_lp_fallbacks=m.stat("blk_lp_fallbacks"), blk_pdhg_iters_sum=m.stat("blk_pdhg_iters_sum"),
-                        ecp_blocks_launches=m.stat("ecp_blocks_launches"), ecp_blocks_fallbacks=m.stat("ecp_blocks_fallbacks"),
-                        ecp_blocks_pdhg_sum=m.stat("ecp_blocks_pdhg_sum")))
+    # per-instance objectives: all atoms of the fused objective at once, then sums by instance
+    val, _ = atom_value_deriv(np.asarray(big.obj_kind), np.asarray(big.obj_p0), np.asarray(big.obj_p1), x[np.asarray(big.obj_col)])
+    optr = big.meta["obj_ptr"]
+    cs = np.concatenate([[0.0], np.cumsum(val)])
+    seg = np.add.reduceat(val, optr[:-1]) if len(val) else np.zeros(len(instances))
+    seg = np.where(np.diff(optr) > 0, seg, 0.0)
+    common = dict(status=status, iters=m.numiters(), numcuts=None, pdhg_iters=m.stat("pdhg_iters"),
+                  blk_lp_launches=m.stat("blk_lp_launches"), blk_lp_fallbacks=m.stat("blk_lp_fallbacks"),
+                  blk_pdhg_iters_sum=m.stat("blk_pdhg_iters_sum"), ecp_blocks_launches=m.stat("ecp_blocks_launches"),
+                  ecp_blocks_fallbacks=m.stat("ecp_blocks_fallbacks"), ecp_blocks_pdhg_sum=m.stat("ecp_blocks_pdhg_sum"))
+    out = [dict(common, objval=float(seg[k] + inst.obj_const), x=x[offs[k]:offs[k + 1]]) for k, inst in enumerate(instances)]
     return out, time.perf_counter() - t0

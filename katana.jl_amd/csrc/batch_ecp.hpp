@@ -34,8 +34,9 @@ struct EcpBatch {
     NlpDev P; const int32_t* nl_rows;                                                                                 // NL rows (global ids)
     // ---- arenas
     const EcpArena* arena;
-    int32_t* rptr; int32_t* rcol; double* rval; double* rsval; double* lo; double* hi; double* y; double* dr; double* loh; double* hih;
-    int32_t* cptr; int32_t* crow; double* cval; double* csval;     // cptr: [ncols_total + nb] (instance b at blk_col[b] + b)
+    int32_t* rptr; uint16_t* rcol; double* rval; double* rsval; double* lo; double* hi; double* y; double* dr; double* loh; double* hih;
+    int32_t* cptr; uint16_t* crow; double* cval; double* csval;    // cptr: [ncols_total + nb] (instance b at blk_col[b] + b); 16-bit local
+                                                                   // indices: 20 instead of 24 bytes per non-zero and PDHG iteration
     double* dc; double* ch; double* lh; double* uh;                // per column (global column indexing)
     int32_t* last_cut;                                             // per NL slot: local row of its newest cut (-1)
     int32_t* cut_prev;                                             // per row: previous cut of the same NL slot (-1): lists for the stall handler
@@ -44,7 +45,7 @@ struct EcpBatch {
     double* res;                                                   // [nb * 8] out: status, ecp iterations, objective, cuts, pdhg iterations, max violation, lp rows, -
     // ---- parameters
     double f_tol, cut_coef_rng, tol_scale, tol_floor, tol_cap, gap_floor, gap_cap, stag_factor;
-    int iter_cap, lp_max_iter, check_every, near_chunk, ruiz_iters, nmax, mmax;
+    int iter_cap, lp_max_iter, check_every, near_chunk, ruiz_iters, power_passes, nmax, mmax;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -72,7 +73,7 @@ __device__ __forceinline__ void ecp_reduce(double (&v)[NQ], int nsum, double* re
 // tail of the batch, is latency-bound).
 struct EcpPre { double a, b, c; };
 template <int G, int T, class PF, class F>
-__device__ __forceinline__ void ecp_spmv(int count, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+__device__ __forceinline__ void ecp_spmv(int count, const int32_t* __restrict__ ptr, const uint16_t* __restrict__ idx,
                                          const double* __restrict__ val, const double* v, PF&& pre, F&& out) {
     constexpr int kGroups = kEcpThreads / G;
     const int lane = threadIdx.x & (G - 1), g0 = threadIdx.x / G;
@@ -127,13 +128,13 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
     const int m_nl = (int)(B.blk_nl[b + 1] - nl0);
     const EcpArena A = B.arena[b];
     int32_t* rptr = B.rptr + A.row0 + b;          // cap_rows + 1 slots per instance
-    int32_t* rcol = B.rcol + A.nnz0;
+    uint16_t* rcol = B.rcol + A.nnz0;
     double* rval = B.rval + A.nnz0;
     double* rsval = B.rsval + A.nnz0;
     double* lo = B.lo + A.row0; double* hi = B.hi + A.row0; double* yv = B.y + A.row0; double* dr = B.dr + A.row0;
     double* loh = B.loh + A.row0; double* hih = B.hih + A.row0;
     int32_t* cptr = B.cptr + c0 + b;              // nb + 1 slots per instance
-    int32_t* crow = B.crow + A.nnz0;
+    uint16_t* crow = B.crow + A.nnz0;
     double* cval = B.cval + A.nnz0;
     double* csval = B.csval + A.nnz0;
     double* dc = B.dc + c0; double* ch = B.ch + c0; double* lh = B.lh + c0; double* uh = B.uh + c0;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
         NNZ = (int)(B.lp_rowptr[lin0 + m_lin] - e0);
         for (int r = tid; r <= m_lin; r += kEcpThreads) rptr[r] = (int32_t)(B.lp_rowptr[lin0 + r] - e0);
         for (int r = tid; r < m_lin; r += kEcpThreads) { lo[r] = B.lp_lo[lin0 + r]; hi[r] = B.lp_hi[lin0 + r]; yv[r] = 0.0; }
-        for (int e = tid; e < NNZ; e += kEcpThreads) { rcol[e] = B.lp_col[e0 + e] - (int32_t)c0; rval[e] = B.lp_val[e0 + e]; }
+        for (int e = tid; e < NNZ; e += kEcpThreads) { rcol[e] = (uint16_t)(B.lp_col[e0 + e] - (int32_t)c0); rval[e] = B.lp_val[e0 + e]; }
         for (int i = tid; i < m_nl; i += kEcpThreads) last_cut[i] = -1;
         for (int j = tid; j < nb; j += kEcpThreads) xg[j] = 0.0;
     }
@@ -192,13 +193,13 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
         for (int r = tid; r < M; r += kEcpThreads)
             for (int e = rptr[r]; e < rptr[r + 1]; ++e) {
                 const int p = atomicAdd(&icnt[rcol[e]], 1);
-                crow[p] = r; cval[p] = rval[e];
+                crow[p] = (uint16_t)r; cval[p] = rval[e];
             }
         __syncthreads();
         for (int j = tid; j < nb; j += kEcpThreads) {                                   // insertion sort by row (short lists)
             const int beg = cptr[j], end = cptr[j + 1];
             for (int a = beg + 1; a < end; ++a) {
-                const int rr = crow[a]; const double vv = cval[a];
+                const uint16_t rr = crow[a]; const double vv = cval[a];
                 int p = a - 1;
                 while (p >= beg && crow[p] > rr) { crow[p + 1] = crow[p]; cval[p + 1] = cval[p]; --p; }
                 crow[p + 1] = rr; cval[p + 1] = vv;
@@ -268,7 +269,8 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
             __syncthreads();
             for (int j = tid; j < nb; j += kEcpThreads) xts[j] = nrm > 0.0 ? xts[j] / nrm : 0.0;
             __syncthreads();
-            for (int pass = 0; pass < 20; ++pass) {
+            const int npow = B.power_passes;
+            for (int pass = 0; pass < npow; ++pass) {
                 ecp_spmv<4, 4>(M, rptr, rcol, rsval, xts, [&](int) { return EcpPre{0.0, 0.0, 0.0}; }, [&](int r, double acc, const EcpPre&) { yts[r] = acc; });
                 __syncthreads();
                 a1[0] = 0.0;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
                 ecp_reduce<1>(a1, 1, red, q);
                 nrm = sqrt(q[0]);
                 __syncthreads();
-                if (pass < 19) for (int j = tid; j < nb; j += kEcpThreads) xts[j] = nrm > 0.0 ? xts[j] / nrm : 0.0;
+                if (pass < npow - 1) for (int j = tid; j < nb; j += kEcpThreads) xts[j] = nrm > 0.0 ? xts[j] / nrm : 0.0;
                 __syncthreads();
             }
             smax = sqrt(nrm);                    // ||A'A v|| with ||v|| = 1 -> sigma_max^2
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
                     dot += xs[cl] * der;
                     mx = nanmax(mx, der);
                     nf |= !isfinite(der);
-                    rcol[dst + (int)(e - beg)] = cl;
+                    rcol[dst + (int)(e - beg)] = (uint16_t)cl;
                     rval[dst + (int)(e - beg)] = der;
                 }
                 dot = group_sum<16>(dot);

@@ -292,7 +292,8 @@ struct Engine {
     bool optimize_blocks_device(int cap_mul);
     DBuf<EcpArena> d_ar;                          // arenas of the device-side loop
     DBuf<int64_t> d_blklin, d_blknl;
-    DBuf<int32_t> e_rptr, e_rcol, e_cptr, e_crow, e_last, e_prev;
+    DBuf<int32_t> e_rptr, e_cptr, e_last, e_prev;
+    DBuf<uint16_t> e_rcol, e_crow;
     DBuf<double> e_ax, e_rval, e_rsval, e_lo, e_hi, e_y, e_dr, e_loh, e_hih, e_cval, e_csval, e_dc, e_ch, e_lh, e_uh, e_res;     // batch_ecp.hpp: the whole ECP loop of every instance in its own workgroup
     bool lp_solve_blocks(double tol_p, double tol_g, double eta, LpResult* R, int64_t max_it);
     double smax_prev = 0.0;
@@ -775,6 +776,10 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     if (d->atom_kind) akind.assign(d->atom_kind, d->atom_kind + nnz0); else akind.assign((size_t)nnz0, 0);
     if (d->p0) p0.assign(d->p0, d->p0 + nnz0); else p0.assign((size_t)nnz0, 0.0);
     if (d->p1) p1.assign(d->p1, d->p1 + nnz0); else p1.assign((size_t)nnz0, 0.0);
+    {
+        const size_t tail = (size_t)std::max<int64_t>(std::max<int64_t>(d->obj_nnz, d->obj_tape_len), (d->obj_kind == KTN_ROW_HOST ? n0 : 0)) + 2;
+        h_col.reserve((size_t)nnz0 + tail); akind.reserve((size_t)nnz0 + tail); p0.reserve((size_t)nnz0 + tail); p1.reserve((size_t)nnz0 + tail);
+    }
     h_rowkind.assign(m_ext, KTN_ROW_SEP);
     {
         int32_t cmin = 0, cmax = -1;
@@ -901,15 +906,18 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     // ---- upload the NLP
     d_rowptr.upload(h_rowptr, stream); d_col.upload(h_col, stream);
     {
-        std::vector<int32_t> colk(h_col.size());
-        std::vector<double2> pp(h_col.size());
-        for (size_t e = 0; e < h_col.size(); ++e) {
-            KTN_REQUIRE(akind[e] <= KTN_ATOM_NEGLOG, "unknown atom kind");
-            colk[e] = h_col[e] | ((int32_t)akind[e] << kKindShift);
-            pp[e] = make_double2(p0[e], p1[e]);
-        }
-        d_colk.upload(colk, stream);
-        d_pp.upload(pp, stream);
+        // packed row programs: the three arrays go up as they are and are packed on the device (k_pack_atoms)
+        uint8_t kmax = 0;
+        for (size_t e = 0; e < akind.size(); ++e) kmax = std::max(kmax, akind[e]);
+        KTN_REQUIRE(kmax <= KTN_ATOM_NEGLOG, "unknown atom kind");
+        const int64_t ne = (int64_t)h_col.size();
+        DBuf<uint8_t> t_ak;
+        DBuf<double> t_p0, t_p1;
+        t_ak.upload(akind, stream); t_p0.upload(p0, stream); t_p1.upload(p1, stream);
+        d_colk.resize((size_t)ne, stream); d_pp.resize((size_t)ne, stream);
+        LAUNCH_1(k_pack_atoms, ne, stream, ne, d_col.p, t_ak.p, t_p0.p, t_p1.p, d_colk.p, d_pp.p);
+        check_launch();
+        sync();                                         // the temporaries are freed on leaving the scope
     }
     d_rconst.upload(rconst, stream);
     d_rowkind.upload(h_rowkind, stream); d_padzero.upload(padzero, stream);
@@ -1023,31 +1031,42 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     // ---- tangent at the origin: linear rows and (linear) objective  model.jl:110-133
     d_xs.zero(stream);
     precompute_all(d_xs.p);
-    std::vector<double> g0 = d_g.to_host(stream), j0 = d_jac.to_host(stream);
+    // the LP rows of the linear constraints are written on the device (k_lin_rows): only the row pointers -- structural --
+    // come from the host; the objective row's slice of (g, J) is all that travels back
     std::vector<int64_t> rp(1, 0);
-    std::vector<int32_t> rc;
+    std::vector<int32_t> rc;                            // host-built rows (the epigraph cut at the vertex) follow the linear rows
     std::vector<double> rv, rlo, rhi;
     numcuts = 0;
+    const int64_t n_lin = (int64_t)lin_rows.size();
+    int64_t nnz_lin = 0;
     {
-        int64_t tot = 0;
-        for (auto i : lin_rows) tot += h_rowptr[i + 1] - h_rowptr[i];
-        rc.resize((size_t)tot); rv.resize((size_t)tot);
-        rp.reserve(lin_rows.size() + 2); rlo.reserve(lin_rows.size() + 1); rhi.reserve(lin_rows.size() + 1);
-        int64_t pos = 0;
-        for (auto i : lin_rows) {
-            // the tangent at the origin: b = g(0) - sum 0 * J = g(0) (the products vanish unless a coefficient is non-finite)
-            const int64_t beg = h_rowptr[i], len = h_rowptr[i + 1] - beg;
-            std::copy(h_col.begin() + beg, h_col.begin() + beg + len, rc.begin() + pos);
-            std::copy(j0.begin() + beg, j0.begin() + beg + len, rv.begin() + pos);
-            double b = g0[i];
-            for (int64_t e = beg; e < beg + len; ++e) b += -0.0 * j0[e];
-            pos += len;
-            rp.push_back(pos);
-            rlo.push_back(l_constr[i] - b);
-            rhi.push_back(u_constr[i] - b);
+        rp.reserve((size_t)n_lin + 2);
+        std::vector<int32_t> lr((size_t)n_lin);
+        for (int64_t k = 0; k < n_lin; ++k) {
+            const int64_t i = lin_rows[(size_t)k];
+            lr[(size_t)k] = (int32_t)i;
+            nnz_lin += h_rowptr[i + 1] - h_rowptr[i];
+            rp.push_back(nnz_lin);
             numcuts += 1;                               // model.jl:77
         }
+        lp_rowptr.resize((size_t)n_lin + 2, stream);
+        KTN_HIP(hipMemcpyAsync(lp_rowptr.p, rp.data(), rp.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        lp_col.resize((size_t)nnz_lin + 1, stream); lp_val.resize((size_t)nnz_lin + 1, stream);
+        lp_lo.resize((size_t)n_lin + 1, stream); lp_hi.resize((size_t)n_lin + 1, stream);
+        DBuf<int32_t> t_lr;
+        t_lr.upload(lr, stream);
+        LAUNCH_1(k_lin_rows, n_lin, stream, n_lin, t_lr.p, d_rowptr.p, d_col.p, d_jac.p, d_g.p, d_lb.p, d_ub.p, lp_rowptr.p, lp_col.p,
+                 lp_val.p, lp_lo.p, lp_hi.p);
+        check_launch();
+        sync();
     }
+    // objective row at the origin: g0[m0] and its Jacobian entries
+    const int64_t ob = h_rowptr[m0], ol = h_rowptr[m0 + 1] - ob;
+    std::vector<double> j0obj((size_t)std::max<int64_t>(ol, 1));
+    double g0obj = 0.0;
+    if (ol > 0) KTN_HIP(hipMemcpyAsync(j0obj.data(), d_jac.p + ob, (size_t)ol * sizeof(double), hipMemcpyDeviceToHost, stream));
+    KTN_HIP(hipMemcpyAsync(&g0obj, d_g.p + m0, sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
     lapl("tangent at origin + LP rows (host)");
     std::vector<double> cvec(n_lp, 0.0);
     c0 = 0.0;
@@ -1055,8 +1074,8 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     if (obj_linear) {
         // gencut(fsep, pt, (0,0), num_constr+1), drop the fictitious aux variable  model.jl:129-133
         for (int64_t e = h_rowptr[m0]; e < h_rowptr[m0 + 1]; ++e)
-            if (h_col[e] < n0) cvec[h_col[e]] += j0[e];
-        c0 = g0[m0];
+            if (h_col[e] < n0) cvec[h_col[e]] += j0obj[(size_t)(e - ob)];
+        c0 = g0obj;
     } else {
         cvec[n0] = 1.0;                                 // @objective(m.linear_model, sense, y)  model.jl:139
         // initial epigraph cut at the bound-box vertex  model.jl:93-97,156-164
@@ -1101,7 +1120,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
                     rc.push_back(h_col[e]);
                     rv.push_back(coef[e - h_rowptr[m0]]);
                 }
-                rp.push_back((int64_t)rc.size());
+                rp.push_back(nnz_lin + (int64_t)rc.size());
                 rlo.push_back(h_lb[m0] - b);
                 rhi.push_back(h_ub[m0] - b);
                 numcuts += 1;
@@ -1109,11 +1128,20 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
         }
     }
     lapl("objective");
-    // ---- LP upload
-    M = (int64_t)rlo.size();
-    NNZ = (int64_t)rc.size();
-    lp_rowptr.upload(rp, stream); lp_col.upload(rc, stream); lp_val.upload(rv, stream);
-    lp_lo.upload(rlo, stream); lp_hi.upload(rhi, stream);
+    // ---- LP: the linear rows are in place (device); rows built on the host (the epigraph cut at the vertex) are appended
+    M = n_lin + (int64_t)rlo.size();
+    NNZ = nnz_lin + (int64_t)rc.size();
+    if (!rlo.empty()) {
+        lp_rowptr.resize((size_t)M + 1, stream); lp_col.resize((size_t)NNZ + 1, stream); lp_val.resize((size_t)NNZ + 1, stream);
+        lp_lo.resize((size_t)M, stream); lp_hi.resize((size_t)M, stream);
+        KTN_HIP(hipMemcpyAsync(lp_rowptr.p + n_lin + 1, rp.data() + n_lin + 1, rlo.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        KTN_HIP(hipMemcpyAsync(lp_col.p + nnz_lin, rc.data(), rc.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        KTN_HIP(hipMemcpyAsync(lp_val.p + nnz_lin, rv.data(), rv.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        KTN_HIP(hipMemcpyAsync(lp_lo.p + n_lin, rlo.data(), rlo.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        KTN_HIP(hipMemcpyAsync(lp_hi.p + n_lin, rhi.data(), rhi.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        sync();
+    }
+    lp_rowptr.n = (size_t)M + 1; lp_col.n = lp_val.n = (size_t)NNZ; lp_lo.n = lp_hi.n = (size_t)M;
     lp_y.resize((size_t)M, stream); lp_y.zero(stream);
     lp_c.upload(cvec, stream); lp_l.upload(lv, stream); lp_u.upload(uv, stream);
     lp_x.resize((size_t)n_lp, stream); lp_x.zero(stream);
@@ -1479,7 +1507,7 @@ bool Engine::optimize_blocks_device(int cap_mul) {
     }
     const size_t lds = (size_t)(3 * blk_nmax + 3 * mmax + (kEcpThreads / 64) * kEcpQ + kEcpQ + 8 + 16) * sizeof(double) +
                        (size_t)(std::max(blk_nmax, mmax) + 4) * sizeof(int32_t);
-    if (lds > 158 * 1024) return false;
+    if (lds > 158 * 1024 || blk_nmax > 65535 || mmax > 65535) return false;      // 16-bit local indices in the arenas
     t_start = std::chrono::steady_clock::now();
     d_ar.upload(ar, stream); d_blklin.upload(blk_lin, stream); d_blknl.upload(blk_nl, stream);
     e_rptr.resize((size_t)row_tot + nb + 1, stream);
@@ -1509,6 +1537,7 @@ bool Engine::optimize_blocks_device(int cap_mul) {
     //  slowest instance against 64 -- 512 x cfg5: max 15 842 -> 5 008, the launch 0.131 -> 0.097 s)
     B.check_every = std::min(B.check_every, 24);
     B.near_chunk = prm.lp_near_check; B.ruiz_iters = prm.lp_ruiz_iters; B.nmax = blk_nmax; B.mmax = mmax;
+    B.power_passes = std::getenv("KTN_ECP_POWER") ? std::atoi(std::getenv("KTN_ECP_POWER")) : 20;
     static size_t lds_set = 0;
     if (lds > lds_set) {
         KTN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ecp_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

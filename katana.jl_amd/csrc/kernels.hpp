@@ -436,6 +436,38 @@ __global__ __launch_bounds__(kBlock) void k_host_scatter(NlpDev P, const int32_t
     for (int64_t e = P.rowptr[r]; e < P.rowptr[r + 1]; ++e) O.jac[e] = jh[e];
 }
 
+// loadproblem!: the packed row programs (col | kind << 29, (p0, p1)) from the caller's separate arrays
+__global__ __launch_bounds__(kBlock) void k_pack_atoms(int64_t nnz, const int32_t* __restrict__ col, const uint8_t* __restrict__ kind,
+                                                       const double* __restrict__ p0, const double* __restrict__ p1,
+                                                       int32_t* __restrict__ colk, double2* __restrict__ pp) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= nnz) return;
+    colk[e] = col[e] | ((int32_t)kind[e] << kKindShift);
+    pp[e] = make_double2(p0[e], p1[e]);
+}
+// loadproblem!: the linear rows of the LP from the tangent at the origin (src/model.jl:110-122): row r of the LP is
+// constraint lin_rows[r]; coefficients = its Jacobian entries at 0, bounds [l - b, u - b] with b = g(0) - sum 0 * J.
+// lp_rowptr is already in place (the row lengths are structural).
+__global__ __launch_bounds__(kBlock) void k_lin_rows(int64_t nlin, const int32_t* __restrict__ lin_rows, const int64_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col, const double* __restrict__ jac,
+                                                     const double* __restrict__ g, const double* __restrict__ lb, const double* __restrict__ ub,
+                                                     const int64_t* __restrict__ lp_rowptr, int32_t* __restrict__ lp_col,
+                                                     double* __restrict__ lp_val, double* __restrict__ lp_lo, double* __restrict__ lp_hi) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= nlin) return;
+    const int32_t i = lin_rows[r];
+    const int64_t beg = rowptr[i], len = rowptr[i + 1] - beg, dst = lp_rowptr[r];
+    double b = g[i];
+    for (int64_t e = 0; e < len; ++e) {
+        const double jv = jac[beg + e];
+        lp_col[dst + e] = col[beg + e];
+        lp_val[dst + e] = jv;
+        b += -0.0 * jv;                              // NaN / Inf coefficients poison the constant, as in linear_oa_cut
+    }
+    lp_lo[r] = lb[i] - b;
+    lp_hi[r] = ub[i] - b;
+}
+
 // Growing row-sparse LP  lo <= A x <= hi  (CSR, rows only ever appended).
 struct LpRows {
     int64_t* rowptr;

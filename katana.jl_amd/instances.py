@@ -250,30 +250,36 @@ def fuse_instances(insts):
     solving all of them at once -- every kernel launch of the engine then serves the whole batch
     (katana_jl_amd.batch.solve_batch(..., fused=True)).  Returns (fused instance, variable offsets)."""
     offs = np.concatenate([[0], np.cumsum([i.n for i in insts])]).astype(np.int64)
+    rps = [np.asarray(i.rowptr) for i in insts]
+    cut = [int(rp[i.m_lin]) for rp, i in zip(rps, insts)]                # first entry of the NL rows of each instance
 
-    def rows_of(i, lo, hi):
-        rp = np.asarray(i.rowptr)
-        a, b = rp[lo], rp[hi]
-        return (np.diff(rp[lo:hi + 1]), np.asarray(i.col)[a:b], np.asarray(i.kind)[a:b], np.asarray(i.p0)[a:b],
-                np.asarray(i.p1)[a:b], np.asarray(i.rconst)[lo:hi], np.asarray(i.l_constr)[lo:hi], np.asarray(i.u_constr)[lo:hi])
+    def cat(attr, dtype=None):
+        """linear-row part of every instance, then the NL-row part of every instance (per entry)"""
+        a = [np.asarray(getattr(i, attr)) for i in insts]
+        out = np.concatenate([x[:c] for x, c in zip(a, cut)] + [x[c:] for x, c in zip(a, cut)])
+        return out if dtype is None else out.astype(dtype, copy=False)
 
-    parts = [rows_of(i, 0, i.m_lin) + (o,) for i, o in zip(insts, offs)] + \
-            [rows_of(i, i.m_lin, i.num_constr) + (o,) for i, o in zip(insts, offs)]
-    lens = np.concatenate([p[0] for p in parts])
+    def cat_rows(attr):
+        a = [np.asarray(getattr(i, attr)) for i in insts]
+        return np.concatenate([x[:i.m_lin] for x, i in zip(a, insts)] + [x[i.m_lin:] for x, i in zip(a, insts)])
+
+    lens = np.concatenate([np.diff(rp[:i.m_lin + 1]) for rp, i in zip(rps, insts)] + [np.diff(rp[i.m_lin:]) for rp, i in zip(rps, insts)])
+    cols = [np.asarray(i.col, dtype=np.int32) for i in insts]
+    o32 = offs.astype(np.int32)
+    col = np.concatenate([x[:c] + o for x, c, o in zip(cols, cut, o32)] + [x[c:] + o for x, c, o in zip(cols, cut, o32)])
     fused = SeparableInstance(
         n=int(offs[-1]), l_var=np.concatenate([i.l_var for i in insts]), u_var=np.concatenate([i.u_var for i in insts]),
         sense=insts[0].sense, rowptr=np.concatenate([[0], np.cumsum(lens)]).astype(np.int64),
-        col=np.concatenate([p[1].astype(np.int64) + p[8] for p in parts]).astype(np.int32),
-        kind=np.concatenate([p[2] for p in parts]).astype(np.uint8), p0=np.concatenate([p[3] for p in parts]),
-        p1=np.concatenate([p[4] for p in parts]), rconst=np.concatenate([p[5] for p in parts]),
-        l_constr=np.concatenate([p[6] for p in parts]), u_constr=np.concatenate([p[7] for p in parts]),
-        obj_col=np.concatenate([np.asarray(i.obj_col, dtype=np.int64) + o for i, o in zip(insts, offs)]).astype(np.int32),
-        obj_kind=np.concatenate([i.obj_kind for i in insts]).astype(np.uint8),
+        col=col, kind=cat("kind", np.uint8), p0=cat("p0"), p1=cat("p1"), rconst=cat_rows("rconst"),
+        l_constr=cat_rows("l_constr"), u_constr=cat_rows("u_constr"),
+        obj_col=np.concatenate([np.asarray(i.obj_col, dtype=np.int32) + o for i, o in zip(insts, o32)]),
+        obj_kind=np.concatenate([i.obj_kind for i in insts]).astype(np.uint8, copy=False),
         obj_p0=np.concatenate([i.obj_p0 for i in insts]), obj_p1=np.concatenate([i.obj_p1 for i in insts]),
         obj_const=float(sum(i.obj_const for i in insts)), xhat=np.concatenate([i.xhat for i in insts]),
         opt_obj=float(sum(i.opt_obj for i in insts)), m_lin=int(sum(i.m_lin for i in insts)),
         m_nl=int(sum(i.m_nl for i in insts)),
         meta=dict(fused=len(insts), lam_sum=float(sum(i.meta.get("lam_sum", 0.0) for i in insts)),
-                  mu_sum=float(sum(i.meta.get("mu_sum", 0.0) for i in insts))))
+                  mu_sum=float(sum(i.meta.get("mu_sum", 0.0) for i in insts)),
+                  obj_ptr=np.concatenate([[0], np.cumsum([len(i.obj_col) for i in insts])]).astype(np.int64)))
     assert all(i.sense == fused.sense for i in insts)
     return fused, offs

@@ -82,9 +82,14 @@ class NLPDescription:
 def SeparableNLP(inst):
     """NLPDescription of a katana_jl_amd.instances.SeparableInstance (or any object with the
     same array attributes)."""
-    rows = np.repeat(np.arange(len(inst.rowptr) - 1), np.diff(inst.rowptr))
-    nonlin = np.bincount(rows[np.asarray(inst.kind) != L.ATOM_LIN], minlength=len(inst.rowptr) - 1)
     m = len(inst.rowptr) - 1
+    rp = np.asarray(inst.rowptr)
+    kind = np.ascontiguousarray(inst.kind, dtype=np.uint8)                       # a row is nonlinear iff one of its atoms is (LIN = 0)
+    if len(kind):
+        nonlin = np.maximum.reduceat(kind, np.minimum(rp[:-1], len(kind) - 1))
+        nonlin[np.diff(rp) == 0] = 0                                             # (reduceat returns an element for an empty slice)
+    else:
+        nonlin = np.zeros(m, dtype=np.uint8)
     return NLPDescription(
         inst.n, inst.rowptr, inst.col, np.zeros(m, dtype=np.uint8), (nonlin == 0).astype(np.uint8), inst.rconst,
         inst.kind, inst.p0, inst.p1,
