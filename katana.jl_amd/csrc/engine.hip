@@ -1876,7 +1876,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     if (!(smax > 0.0)) smax = fro;
     const double eta_safe = 0.998 / std::max(identity_scaling ? fro : std::min(1.0, fro), 1e-12);
     double eta = std::max(0.998 / std::max(smax, 1e-12), eta_safe);
-    int stall = 0, flat_rows = 0, consolidations = 0, infeas_hits = 0;
+    int stall = 0, grow = 0, flat_rows = 0, consolidations = 0, infeas_hits = 0;
     double pobj_h[3] = {1e300, -1e300, 1e300}, pviol_h[3] = {1e300, -1e300, 1e300};
     double r_last_check = 0.0;
     sync();
@@ -2026,9 +2026,14 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         // the LP is not solved means eta * sigma_max > 1 -> shrink eta and restart from the current point
         if (k > 0 && eta > eta_safe * (1.0 + 1e-12)) {
             stall = (r2 < 0.0 || (r_last_check > 0.0 && r > 0.97 * r_last_check && r < 1.03 * r_last_check)) ? stall + 1 : 0;
-            if (stall >= 3 || r2 < 0.0) {
+            // ... and the other face of the same fault: the residual GROWS check after check, far above the residual the
+            // period started with (a non-expansive step never does that for long; seen on cfg3 seeds 28/29: r0 = 6 -> 87 -> 530
+            // -> 1e5 over 10 000 iterations until the flat-residual rule above finally fired).  Two growing checks above 5 r0.
+            grow = (r > 5.0 * r0 && r_last_check > 0.0 && r > r_last_check) ? grow + 1 : 0;
+            if (stall >= 3 || r2 < 0.0 || grow >= 2) {
                 eta = std::max(eta_safe, 0.85 * eta);
-                stall = 0;
+                if (grow >= 2) stats["lp_divergence_backoffs"] += 1.0;
+                stall = 0; grow = 0;
                 restart = true;
                 stats["lp_eta_backoffs"] += 1.0;
             }
