@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
         int lp_status = KTN_STATUS_USERLIMIT;
         double pobj = 0.0;
         const int plain_len = B.check_every - 1;
-        const double stall_accept = (tol_p > floor_p * (1.0 + 1e-9)) ? 10.0 : 2.0;
+        const double stall_accept = (tol_p > floor_p * (1.0 + 1e-9)) ? 10.0 : 3.0;
         while (it < B.lp_max_iter) {
             const double tau = eta / om, sigma = eta * om, inv_sigma = 1.0 / sigma;
             if (plain_next) {
@@ -398,10 +398,10 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
                 if (B.stag_factor > 0.0 && !done) {
                     const double f = 0.1 * tol_g * (1.0 + fabs(po));
                     const bool flat = fabs(po - st[3]) <= f && fabs(po - st[4]) <= f && fabs(po - st[5]) <= f;
-                    if (flat && pviol <= tol_p && gap <= B.stag_factor * tol_g && dres_ok) done = true;
-                    if (!done && gap <= tol_g && dres_ok && pviol <= stall_accept * tol_p && fabs(pviol - st[6]) <= 0.02 * pviol &&
-                        fabs(pviol - st[7]) <= 0.02 * pviol && fabs(pviol - st[8]) <= 0.02 * pviol)
-                        done = true;
+                    const bool plateau = pviol <= stall_accept * tol_p && fabs(pviol - st[6]) <= 0.02 * pviol &&
+                                         fabs(pviol - st[7]) <= 0.02 * pviol && fabs(pviol - st[8]) <= 0.02 * pviol;
+                    if (flat && (pviol <= tol_p || plateau) && gap <= B.stag_factor * tol_g && dres_ok) done = true;
+                    if (!done && gap <= tol_g && dres_ok && plateau) done = true;
                 }
                 st[8] = st[7]; st[7] = st[6]; st[6] = pviol; st[5] = st[4]; st[4] = st[3]; st[3] = po;
                 int action = 0;

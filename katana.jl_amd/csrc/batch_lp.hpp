@@ -304,10 +304,10 @@ __global__ __launch_bounds__(kBlkThreads) void k_pdhg_blocks(BlkLp P) {
             if (P.stag_factor > 0.0 && !done) {
                 const double scale = 1.0 + fabs(pobj), f = 0.1 * P.tol_g * scale;
                 const bool flat = fabs(pobj - pobj_h0) <= f && fabs(pobj - pobj_h1) <= f && fabs(pobj - pobj_h2) <= f;
-                if (flat && pviol <= P.tol_p && gap <= P.stag_factor * P.tol_g && dres_ok) done = true;
-                if (!done && gap <= P.tol_g && dres_ok && pviol <= P.stall_accept * P.tol_p && fabs(pviol - pv_h0) <= 0.02 * pviol &&
-                    fabs(pviol - pv_h1) <= 0.02 * pviol && fabs(pviol - pv_h2) <= 0.02 * pviol)
-                    done = true;
+                const bool plateau = pviol <= P.stall_accept * P.tol_p && fabs(pviol - pv_h0) <= 0.02 * pviol &&
+                                     fabs(pviol - pv_h1) <= 0.02 * pviol && fabs(pviol - pv_h2) <= 0.02 * pviol;
+                if (flat && (pviol <= P.tol_p || plateau) && gap <= P.stag_factor * P.tol_g && dres_ok) done = true;
+                if (!done && gap <= P.tol_g && dres_ok && plateau) done = true;
             }
             pv_h2 = pv_h1; pv_h1 = pv_h0; pv_h0 = pviol;
             pobj_h2 = pobj_h1; pobj_h1 = pobj_h0; pobj_h0 = pobj;
