@@ -106,7 +106,7 @@ typedef struct {
     int32_t lp_ruiz_iters;  /* 10                                                   */
     double  lp_tol_scale;   /* 0.1     LP row tolerance = lp_tol_scale * max viol.  */
     double  lp_tol_floor;   /* 0.3     ... floored at lp_tol_floor * f_tol          */
-    double  lp_tol_cap;     /* 0.3     ... capped                                   */
+    double  lp_tol_cap;     /* 10      ... capped                                   */
     double  lp_gap_floor;   /* 1e-7    relative duality-gap tolerance floor         */
     double  lp_gap_cap;     /* 1e-2                                                 */
     int32_t lp_dual_inherit;/* 1       new cut of NL row i inherits the dual of its
