@@ -125,7 +125,7 @@ typedef struct {
                                        LP is solved exactly by a dual active-set kernel (what the reference's
                                        simplex does on its small test models); 0 = never, < 0 = always exact */
     /* deepest-cut selection (the north star's "select deepest cuts"; the reference cuts every violated row, src/model.jl:272-283) */
-    double  cut_cap_factor; /* 2.0     when more than max(cut_cap_factor * num_var, cut_cap_min) NL rows are violated, only that
+    double  cut_cap_factor; /* 1.0     when more than max(cut_cap_factor * num_var, cut_cap_min) NL rows are violated, only that
                                        many of the deepest (largest g - ub / lb - g) get a cut in this iteration; the stop
                                        rule still needs EVERY row within f_tol.  0 = cut every violated row            */
     int64_t cut_cap_min;    /* 10000                                                                                    */

@@ -2402,7 +2402,7 @@ void ktn_default_params(ktn_params* p) {
     p->lp_dual_inherit = 1; p->profile = 0;
     p->purge_age = 2; p->purge_margin = 1e-3; p->purge_min_frac = 0.05; p->purge_min_rows = 2000;
     p->lp_dense_after = 5000;
-    p->cut_cap_factor = 2.0; p->cut_cap_min = 10000;
+    p->cut_cap_factor = 1.0; p->cut_cap_min = 10000;
     p->lp_stag_factor = 100.0;
     p->lp_ruiz_warm = 0; p->lp_tiled_nnz = 4000000; p->lp_near_check = 7; p->dedupe_eps = 1e-6;
     p->polish_factor = 1e-3; p->polish_max_var = 32; p->polish_max_iter = 30;
