@@ -533,12 +533,21 @@ struct Engine {
 #undef KTN_BLK_LAUNCH
             hipExtLaunchKernelGGL(k_sep_combine, dim3(ceil_div(m_nl, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, d_slots.p, m_nl, blk_nb,
                                   d_part.p, f_tol, O);
-        } else if (prm.profile) {
-            const size_t ea = ev_get(), eb = ev_get();
-            LAUNCH_G_EV(grp_sweep, k_sep_eval, m_nl, stream, ev_pool[ea], ev_pool[eb], P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O);
-            ev_recs.push_back({2, ea, eb, sweep_bytes});
         } else {
-            LAUNCH_G(grp_sweep, k_sep_eval, m_nl, stream, P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O);
+            // many short rows: several rows per lane group (k_sep_sweep) once one row per group would make more wavefronts
+            // than the chip holds several times over; small sweeps keep one row per group and all the parallelism
+            static const int rows_env = std::getenv("KTN_SWEEP_ROWS") ? std::atoi(std::getenv("KTN_SWEEP_ROWS")) : 0;
+            const int64_t waves1 = m_nl * grp_sweep / 64, resident = (int64_t)num_cus * 32;
+            const int R = rows_env > 0 ? rows_env : (waves1 >= 16 * resident ? 4 : waves1 >= 8 * resident ? 2 : 1);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (prm.profile) {
+                const size_t ea = ev_get(), eb = ev_get();
+                e0 = ev_pool[ea]; e1 = ev_pool[eb];
+                ev_recs.push_back({2, ea, eb, sweep_bytes});
+            }
+            if (R >= 4) LAUNCH_GB_EV(grp_sweep, k_sep_sweep, 4, ceil_div(m_nl, (int64_t)4), stream, e0, e1, P, d_nlrows.p, m_nl, d_x, f_tol, O);
+            else if (R >= 2) LAUNCH_GB_EV(grp_sweep, k_sep_sweep, 2, ceil_div(m_nl, (int64_t)2), stream, e0, e1, P, d_nlrows.p, m_nl, d_x, f_tol, O);
+            else LAUNCH_G_EV(grp_sweep, k_sep_eval, m_nl, stream, e0, e1, P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O);
         }
         if (n_tape_nl > 0 || n_host_nl > 0) {
             LAUNCH_1(k_tape_eval, n_tape_nl, stream, P, d_taperows_nl.p, n_tape_nl, d_x, O);
