@@ -1663,12 +1663,34 @@ void Engine::launch_x(const SpMat& AT, double tau, double w, double rho, bool up
 // y-step (k_pdhg_y_chk gathers xt and x anyway); the column side needs A'yt and is one G-lanes-per-column pass.
 void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double sigma) {
     const int64_t n = n_lp, m = M;
-    launch_x(AT, tau, 0.0, 1.0, false, nullptr, nullptr);
     const int64_t thr = n_long > 0 ? kLongRow : (int64_t)1 << 62;
     const int64_t brow = ceil_div(std::max<int64_t>(m, 1) * grp_rows, kBlock), bcol = ceil_div(n * grp_cols, kBlock);
     chk_part.resize((size_t)(brow + n_long + bcol) * kChkQ, stream);
     double* prow = chk_part.p;
     double* pcol = chk_part.p + (size_t)(brow + n_long) * kChkQ;
+    static const bool tiled_chk_off = std::getenv("KTN_NO_TILED_CHECK") != nullptr;
+    if (tiled_on && m > 0 && !row_sharded() && !tiled_chk_off) {
+        // the four SpMV passes of a check through the tiled copy (kernels.hpp "check iteration on the tiled copy")
+        const int64_t brow_t = ceil_div(m, (int64_t)kBlock), bcol_t = ceil_div(n, (int64_t)kBlock);      // <= brow, bcol
+        launch_tiled(tAT, n, m, yh.p, nullptr);
+        LAUNCH_1(k_x_epilogue_chk, n, stream, n, tAT.pcnt.p, tpart.p, xh.p, xth.p, ch.p, lh.p, uh.p, tau);
+        launch_tiled(tA, m, n, xth.p, nullptr);
+        LAUNCH_1(k_tile_vec, m, stream, m, tA.pcnt.p, tpart.p, pw.p);
+        launch_tiled(tA, m, n, xh.p, nullptr);
+        LAUNCH_1(k_y_epilogue_chk, m, stream, m, tA.pcnt.p, tpart.p, pw.p, (n_long > 0 ? A.ptr : (const int64_t*)nullptr), thr, yh.p, y0h.p,
+                 yth.p, loh.p, hih.p, dr.p, sigma, prow);
+        if (n_long > 0)
+            hipLaunchKernelGGL((k_pdhg_y_long<true>), dim3((unsigned)n_long), dim3(kLongBlock), 0, stream, d_longrows.p, A, xth.p, xh.p,
+                               yh.p, y0h.p, yth.p, loh.p, hih.p, dr.p, sigma, 0.0, 1.0, prow + (size_t)brow_t * kChkQ);
+        chk_nrow = (int)(brow_t + n_long);
+        launch_tiled(tAT, n, m, yth.p, nullptr);
+        LAUNCH_1(k_tile_vec, n, stream, n, tAT.pcnt.p, tpart.p, pv.p);
+        LAUNCH_1(k_chk_cols_vec, n, stream, n, pv.p, xh.p, xth.p, x0h.p, ch.p, lh.p, uh.p, dc.p, pcol);
+        chk_ncol = (int)bcol_t;
+        hipLaunchKernelGGL(k_chk_final, dim3(2 * kChkQ), dim3(kRedBlocks), 0, stream, prow, chk_nrow, pcol, chk_ncol, chkout.p);
+        return;
+    }
+    launch_x(AT, tau, 0.0, 1.0, false, nullptr, nullptr);
     if (m > 0) {
         LAUNCH_G(grp_rows, k_pdhg_y_chk, m, stream, m, A, xth.p, xh.p, yh.p, y0h.p, yth.p, loh.p, hih.p, dr.p, sigma, thr, prow);
         if (n_long > 0)

@@ -1432,6 +1432,43 @@ __global__ __launch_bounds__(kBlock) void k_y_epilogue(int64_t m, const int32_t*
     y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0i;
 }
 
+// ---- check iteration on the tiled copy: four tiled passes (A'y, A xt, A x, A'yt) with element-wise epilogues; the sums are
+// those of k_pdhg_x<G, false> / k_pdhg_y_chk / k_chk_cols (the CSR check kernels cost 310 us per check on cfg4's large
+// LPs, 4.5 plain iterations; this form 150 us) ------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_x_epilogue_chk(int64_t n, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
+                                                           const double* __restrict__ x, double* __restrict__ xt,
+                                                           const double* __restrict__ c, const double* __restrict__ l,
+                                                           const double* __restrict__ u, double tau) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    xt[j] = clampd(x[j] - tau * (c[j] - tile_pieces_sum(part, j, n, pcnt)), l[j], u[j]);
+}
+__global__ __launch_bounds__(kBlock) void k_tile_vec(int64_t n_out, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
+                                                     double* __restrict__ out) {
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (o < n_out) out[o] = tile_pieces_sum(part, o, n_out, pcnt);
+}
+// part holds the pieces of A x, axt_v the vector A xt
+__global__ __launch_bounds__(kBlock) void k_y_epilogue_chk(int64_t m, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
+                                                           const double* __restrict__ axt_v, const int64_t* __restrict__ rowptr,
+                                                           int64_t long_thresh, const double* __restrict__ y, const double* __restrict__ y0,
+                                                           double* __restrict__ yt, const double* __restrict__ lo,
+                                                           const double* __restrict__ hi, const double* __restrict__ dr, double sigma,
+                                                           double* __restrict__ partials) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    ChkAcc a; a.init();
+    const bool mine = i < m && !(rowptr && rowptr[i + 1] - rowptr[i] > long_thresh);      // long rows: k_pdhg_y_long<true>
+    if (mine) {
+        const double yv = y[i], loi = lo[i], hii = hi[i], axt = axt_v[i];
+        const double axk = tile_pieces_sum(part, i, m, pcnt);
+        const double v = yv - sigma * (2.0 * axt - axk);
+        const double ytv = v + sigma * clampd(-v / sigma, loi, hii);
+        yt[i] = ytv;
+        chk_row_accumulate(a, ytv, yv, y0[i], axt, axk, loi, hii, dr[i]);
+    }
+    chk_block_store<kBlock, kChkRowMask>(a, partials);
+}
+
 // ---- building the tiled copy (once per LP solve, after the scaling): count -> scan per (tile, block) -> fill ----------
 // cnt is zeroed, shaped like bptr; thread o owns the shorts [.. + t + 1] of its tile's blocks (no atomics needed)
 __global__ __launch_bounds__(kBlock) void k_tile_count(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
