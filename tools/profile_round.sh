@@ -29,6 +29,6 @@ run_stats sweep_hbm $R/tools/sweep_bench.py cfg3_hbm 20
 run_pmc sweep_hbm FETCH_SIZE $R/tools/sweep_bench.py cfg3_hbm 8
 cd $R
 python3 bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
-python3 tools/spmv_bench.py 1000000 40 > $OUT/spmv_hbm.json 2>/dev/null
-python3 tools/sweep_bench.py cfg3_hbm 20 > $OUT/sweep_hbm.json 2>/dev/null
+python3 tools/spmv_bench.py 1000000 40 2>/dev/null | tail -1 > $OUT/spmv_hbm.json
+python3 tools/sweep_bench.py cfg3_hbm 20 2>/dev/null | tail -1 > $OUT/sweep_hbm.json
 ls -la $OUT
