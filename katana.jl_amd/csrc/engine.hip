@@ -261,6 +261,7 @@ struct Engine {
     static constexpr int kMaxChunk = 512;
     int64_t n_long = 0;
     static constexpr int64_t kLongRow = 2048;
+    int64_t max_row_len = (int64_t)1 << 62;    // longest row the LP can hold (NLP structure rows + appended rows): no scan for long rows below kLongRow
     double omega = 1.0;
     bool have_omega = false;
     int grp_rows = 8, grp_cols = 8;
@@ -914,6 +915,8 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     lapl("tapes, bounds, nl list");
     // ---- upload the NLP
     d_rowptr.upload(h_rowptr, stream); d_col.upload(h_col, stream);
+    max_row_len = 2;                                   // (the bound-box vertex row and other engine-made rows are short)
+    for (size_t i = 0; i + 1 < h_rowptr.size(); ++i) max_row_len = std::max(max_row_len, h_rowptr[i + 1] - h_rowptr[i]);
     {
         // packed row programs: the three arrays go up as they are and are packed on the device (k_pack_atoms)
         uint8_t kmax = 0;
@@ -1583,7 +1586,7 @@ bool Engine::optimize_blocks_device(int cap_mul) {
 
 void Engine::find_long_rows() {
     n_long = 0;
-    if (M == 0) return;
+    if (M == 0 || max_row_len <= kLongRow) return;      // no row of this problem can be long: no scan, no round trip
     d_longrows.resize((size_t)M, stream);
     KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
     LAUNCH_1(k_find_long, M, stream, M, lp_rowptr.p, kLongRow, d_longrows.p, d_anynf.p + 1);
@@ -1855,6 +1858,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     // last ||A^||_2 <= 1 is guaranteed (Pock & Chambolle 2011, Lemma 2): eta_safe = 0.998; always using
     // it costs 40 % (cfg3) to 170 % (cfg2) more PDHG iterations than the estimate.
     double smax = 0.0;
+    bool have_power = false;
     // sigma_max of the previous solve is reused while the matrix has grown by less than KTN_SMAX_REUSE (a fraction of its
     // rows) since the estimate was made (development switch, default off)
     static const double smax_reuse = std::getenv("KTN_SMAX_REUSE") ? std::atof(std::getenv("KTN_SMAX_REUSE")) : 0.0;
@@ -1896,14 +1900,30 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
                 allreduce(pv.p, (size_t)n, 0);
             }
         }
-        double nv2 = 0.0;
-        KTN_HIP(hipMemcpyAsync(&nv2, nrm, 8, hipMemcpyDeviceToHost, stream));
-        sync();
+        have_power = true;
+    }
+    // The scalars the loop needs -- the power iteration's ||A'A v||, ||A^||_F^2, ||c^||^2 and the finite parts of ||lo^||^2, ||hi^||^2 --
+    // are all queued into slots behind chkout's check sums and come back with ONE copy and ONE host synchronisation (they
+    // were five round trips, each idling the GPU for ~30 us).
+    double* slots = chkout.p + 2 * kChkQ;           // [1] power, [2] fro2, [3] nc2, [4] |lo|^2, [5] |hi|^2
+    auto reduce_into = [&](bool finite_sq, int64_t cnt, const double* a, int slot) {
+        if (finite_sq) hipLaunchKernelGGL(k_finite_sq_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, cnt, a, partials.p);
+        else hipLaunchKernelGGL(k_dot_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, cnt, a, a, partials.p);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, slots + slot);
+    };
+    if (NNZ > 0) reduce_into(false, NNZ, r_sval.p, 2);
+    reduce_into(false, n, ch.p, 3);
+    if (m > 0) { reduce_into(true, m, loh.p, 4); reduce_into(true, m, hih.p, 5); }
+    double hs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    KTN_HIP(hipMemcpyAsync(hs, slots, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    sync();
+    if (have_power) {
+        const double nv2 = hs[1];
         smax = (nv2 > 0.0) ? std::sqrt(std::sqrt(nv2)) : 0.0;     // sigma_max^2 ~ ||A'A v||
         if (mode == 0) { smax_prev = smax; smax_rows = m; }
     }
     lap("lp_power_time_s", tp);
-    double fro2 = (NNZ > 0) ? dev_dot(NNZ, r_sval.p, r_sval.p) : 0.0;                  // ||A||_2 <= ||A||_F
+    double fro2 = (NNZ > 0) ? hs[2] : 0.0;                                              // ||A||_2 <= ||A||_F
     allreduce_host(&fro2, 1, 0);
     const double fro = std::sqrt(fro2);
     if (!(smax > 0.0)) smax = fro;
@@ -1912,10 +1932,9 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     int stall = 0, grow = 0, flat_rows = 0, consolidations = 0, infeas_hits = 0;
     double pobj_h[3] = {1e300, -1e300, 1e300}, pviol_h[3] = {1e300, -1e300, 1e300};
     double r_last_check = 0.0;
-    sync();
     stats["lp_setup_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    const double nc2 = dev_dot(n, ch.p, ch.p);
-    double nb2 = (m > 0) ? dev_finite_sq(m, loh.p) + dev_finite_sq(m, hih.p) : 0.0;
+    const double nc2 = hs[3];
+    double nb2 = (m > 0) ? hs[4] + hs[5] : 0.0;
     allreduce_host(&nb2, 1, 0);
     const double omega_ref = (nc2 > 0.0 && nb2 > 0.0) ? std::sqrt(nc2 / nb2) : 1.0;
     double om = (have_omega && mode == 0) ? omega : omega_ref;
@@ -2861,6 +2880,7 @@ int ktn_lp_append_rows_nl(ktn_handle h, int64_t nrows, const int64_t* rowptr, co
         for (int64_t i = 0; i < nrows; ++i) {
             KTN_REQUIRE(rowptr[i + 1] >= rowptr[i], "append: rowptr not monotone");
             rp[(size_t)i] = rowptr[i + 1] - rowptr[0] + e->NNZ;
+            e->max_row_len = std::max(e->max_row_len, rowptr[i + 1] - rowptr[i]);
         }
         for (int64_t k = 0; k < nz; ++k) KTN_REQUIRE(col[rowptr[0] + k] >= 0 && col[rowptr[0] + k] < e->n_lp, "append: column out of range");
         hipStream_t s = e->stream;
