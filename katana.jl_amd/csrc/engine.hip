@@ -1637,7 +1637,11 @@ void Engine::launch_x(const SpMat& AT, double tau, double w, double rho, bool up
     if (row_sharded()) {
         // local partial of A'y, summed over the ranks, then the element-wise primal step on the replicated x
         if (M == 0) LAUNCH_1(k_fill, n, stream, n, pv.p, 0.0);
-        if (e0) LAUNCH_G_EV(grp_cols, k_spmv, n, stream, e0, e1, n, AT, yh.p, pv.p);
+        if (tiled_on && M > 0) {                          // this rank's block is large: its partial A_r'y_r from the tiled copy
+            launch_tiled(tAT, n, M, yh.p, e0);
+            hipExtLaunchKernelGGL(k_tile_vec, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, n, tAT.pcnt.p, tpart.p, pv.p);
+        }
+        else if (e0) LAUNCH_G_EV(grp_cols, k_spmv, n, stream, e0, e1, n, AT, yh.p, pv.p);
         else LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, yh.p, pv.p);
         allreduce(pv.p, (size_t)n, 0);
         if (update) LAUNCH_1(k_x_prox<true>, n, stream, n, pv.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
@@ -1672,11 +1676,19 @@ void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double si
     double* prow = chk_part.p;
     double* pcol = chk_part.p + (size_t)(brow + n_long) * kChkQ;
     static const bool tiled_chk_off = std::getenv("KTN_NO_TILED_CHECK") != nullptr;
-    if (tiled_on && m > 0 && !row_sharded() && !tiled_chk_off) {
-        // the four SpMV passes of a check through the tiled copy (kernels.hpp "check iteration on the tiled copy")
+    if (tiled_on && m > 0 && !tiled_chk_off) {
+        // the four SpMV passes of a check through the tiled copy (kernels.hpp "check iteration on the tiled copy"); row-sharded:
+        // the two column-side vectors are this rank's partials and are summed over the ranks -- the same sequence of
+        // collectives as the CSR form below, so ranks may differ in which form they run
         const int64_t brow_t = ceil_div(m, (int64_t)kBlock), bcol_t = ceil_div(n, (int64_t)kBlock);      // <= brow, bcol
         launch_tiled(tAT, n, m, yh.p, nullptr);
-        LAUNCH_1(k_x_epilogue_chk, n, stream, n, tAT.pcnt.p, tpart.p, xh.p, xth.p, ch.p, lh.p, uh.p, tau);
+        if (row_sharded()) {
+            LAUNCH_1(k_tile_vec, n, stream, n, tAT.pcnt.p, tpart.p, pv.p);
+            allreduce(pv.p, (size_t)n, 0);
+            LAUNCH_1(k_x_prox<false>, n, stream, n, pv.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, 0.0, 1.0);
+        } else {
+            LAUNCH_1(k_x_epilogue_chk, n, stream, n, tAT.pcnt.p, tpart.p, xh.p, xth.p, ch.p, lh.p, uh.p, tau);
+        }
         launch_tiled(tA, m, n, xth.p, nullptr);
         LAUNCH_1(k_tile_vec, m, stream, m, tA.pcnt.p, tpart.p, pw.p);
         launch_tiled(tA, m, n, xh.p, nullptr);
@@ -1688,9 +1700,14 @@ void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double si
         chk_nrow = (int)(brow_t + n_long);
         launch_tiled(tAT, n, m, yth.p, nullptr);
         LAUNCH_1(k_tile_vec, n, stream, n, tAT.pcnt.p, tpart.p, pv.p);
+        if (row_sharded()) allreduce(pv.p, (size_t)n, 0);
         LAUNCH_1(k_chk_cols_vec, n, stream, n, pv.p, xh.p, xth.p, x0h.p, ch.p, lh.p, uh.p, dc.p, pcol);
         chk_ncol = (int)bcol_t;
         hipLaunchKernelGGL(k_chk_final, dim3(2 * kChkQ), dim3(kRedBlocks), 0, stream, prow, chk_nrow, pcol, chk_ncol, chkout.p);
+        if (row_sharded()) {                            // row sums: every rank's rows; column sums are identical already
+            allreduce(chkout.p, 12, 0);
+            allreduce(chkout.p + 12, 4, 1);
+        }
         return;
     }
     launch_x(AT, tau, 0.0, 1.0, false, nullptr, nullptr);
@@ -1842,9 +1859,9 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         // 0.49 s with the CSR kernels; cfg4: 9 500 per unit)
         const int64_t units_t = ceil_div(M, (int64_t)kTileOut) * ceil_div(n_lp, (int64_t)kTileIn);
         const int64_t units_tt = ceil_div(n_lp, (int64_t)kTileOut) * ceil_div(M, (int64_t)kTileIn);
-        tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn && !row_sharded() &&
+        tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn &&
                    NNZ >= 4096 * std::max(units_t, units_tt);
-        if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0 && !row_sharded();
+        if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0;
         if (tiled_on) {
             auto tt = std::chrono::steady_clock::now();
             tiled_on = build_tiled(tA, M, n_lp, lp_rowptr.p, lp_col.p, r_sval.p, kLongRow) &&
@@ -2204,9 +2221,9 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
         // 0.49 s with the CSR kernels; cfg4: 9 500 per unit)
         const int64_t units_t = ceil_div(M, (int64_t)kTileOut) * ceil_div(n_lp, (int64_t)kTileIn);
         const int64_t units_tt = ceil_div(n_lp, (int64_t)kTileOut) * ceil_div(M, (int64_t)kTileIn);
-        tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn && !row_sharded() &&
+        tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn &&
                    NNZ >= 4096 * std::max(units_t, units_tt);
-        if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0 && !row_sharded();
+        if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0;
         if (tiled_on) {
             auto tt = std::chrono::steady_clock::now();
             tiled_on = build_tiled(tA, M, n_lp, lp_rowptr.p, lp_col.p, r_sval.p, kLongRow) &&

@@ -298,8 +298,10 @@ def test_row_sharded_iteration_equals_the_unsharded_one_over_gloo():
         assert np.array_equal(out[r][3], [3.0, -2.0, 14.0]) and np.array_equal(out[r][5], [2.0, 0.0, 7.0])
 
 
-def _worker_rowshard_gpu(rank, world, port, out, inst_kw):
+def _worker_rowshard_gpu(rank, world, port, out, inst_kw, tiled=False):
     sys.path.insert(0, ROOT)
+    if tiled:
+        os.environ["KTN_TILED"] = "1"          # every LP of this process runs its steps and checks from the tiled copies
     import torch.distributed as dist
     import katana_jl_amd as ktn
     from katana_jl_amd.distributed import RowShardedKatanaModel
@@ -315,7 +317,8 @@ def _worker_rowshard_gpu(rank, world, port, out, inst_kw):
     # (b) the whole ECP solve
     m2 = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0), inst, rank, world, dist)
     status = m2.optimize()
-    out[rank] = (lp, status, m2.getobjval(), m2.getsolution(), m2.numiters(), m2.numcuts_global(), m2.lp_num_rows())
+    out[rank] = (lp, status, m2.getobjval(), m2.getsolution(), m2.numiters(), m2.numcuts_global(), m2.lp_num_rows(),
+                 m.stat("lp_tiled_builds") + m2.stat("lp_tiled_builds"))
     dist.destroy_process_group()
 
 
@@ -348,6 +351,26 @@ def test_two_rank_row_sharded_lp_equals_the_single_gpu_lp():
     assert abs(out[0][2] - inst.opt_obj) <= planted_obj_bound(inst)
     assert max_nl_violation(inst, out[0][3]) <= 1e-6 * (1 + 1e-6)
     assert out[0][5] == out[1][5] >= inst.m_lin and out[0][6] + out[1][6] >= inst.m_lin
+
+
+@pytest.mark.gpu
+def test_two_rank_row_sharded_lp_through_the_tiled_copies():
+    """the same with every rank's block served by the tiled SpMV (what a rank of a 2-GPU cfg4 run does: 7e6 local entries): the
+    partial A_r'y_r comes from k_spmv_tiled + k_tile_vec before the all-reduce, the checks from the tiled passes; both ranks end
+    with the same x, at the planted optimum"""
+    import katana_jl_amd as ktn
+    from helpers import max_nl_violation, planted_obj_bound
+    world = 2
+    inst_kw = dict(n=20000, m_nl=2000, k=16, family="explog", seed=3)
+    out = mp.Manager().dict()
+    mp.spawn(_worker_rowshard_gpu, args=(world, _free_port(), out, inst_kw, True), nprocs=world, join=True)
+    inst = ktn.instances.make_instance(**inst_kw)
+    for r in range(world):
+        assert out[r][0][0] == "Optimal" and out[r][1] == "Optimal" and out[r][7] >= 2
+    assert out[0][0][1] == out[1][0][1]
+    assert out[0][2] == out[1][2] and np.array_equal(out[0][3], out[1][3]) and out[0][4] == out[1][4]
+    assert abs(out[0][2] - inst.opt_obj) <= planted_obj_bound(inst)
+    assert max_nl_violation(inst, out[0][3]) <= 1e-6 * (1 + 1e-6)
 
 
 def _worker_rccl_one_rank(rank, world, port, out):
