@@ -225,6 +225,10 @@ struct Engine {
     int64_t M = 0, NNZ = 0, M_base = 0, NNZ_base = 0;
     int64_t numcuts = 0, numcuts_base = 0;
     bool lp_dirty = true;
+    // matrix version: bumped wherever rows are appended or removed.  A re-solve of the SAME matrix (the floor-tolerance re-solve
+    // of an iteration that found every row satisfied) reuses the scaling, the tiled copies and the sigma_max estimate.
+    uint64_t lp_version = 1, scaled_version = 0, smax_version = 0;
+    bool scaled_identity = false;
     bool sharded_rows = false;   // rows were appended/truncated from the host: cut lists are not tracked ...
     bool glists = false;         // ... unless the host supplies global NL-row ids (ktn_lp_enable_global_lists)
     int64_t nl_total = 0;
@@ -276,7 +280,7 @@ struct Engine {
         TiledMat view() const { return TiledMat{segstart.p, bptr.p, idx.p, val.p, nb_in}; }
     } tA, tAT;
     DBuf<double> tpart;
-    bool tiled_on = false;
+    bool tiled_on = false, tiled_built = false;
     void launch_tiled(const TiledBuf& T, int64_t n_out, int64_t n_in, const double* in, hipEvent_t e0) {
         hipExtLaunchKernelGGL(k_spmv_tiled, dim3((unsigned)T.grid), dim3(kTileThreads), 0, stream, e0, nullptr, 0, n_out, n_in, T.tiles,
                               T.view(), in, tpart.p);
@@ -624,7 +628,7 @@ struct Engine {
             NNZ += nnzV;
             numcuts += V;
             last_sweep_cuts = V;
-            lp_dirty = true;
+            lp_dirty = true; ++lp_version;
         }
         sync();
         stats["sep_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1187,7 +1191,7 @@ void Engine::reset() {
     d_lastcut.upload(neg1, stream);
     d_age.resize((size_t)std::max<int64_t>(M, 1), stream);
     d_age.zero(stream);
-    lp_dirty = true; have_omega = false; have_precompute = false; sharded_rows = false; scal_rows = 0; smax_rows = 0;
+    lp_dirty = true; ++lp_version; have_omega = false; have_precompute = false; sharded_rows = false; scal_rows = 0; smax_rows = 0;
     blocks_built_rows = -1;
     if (d_blkomega.n) d_blkomega.zero(stream);
     if (ds_valid.n) ds_valid.zero(stream);
@@ -1299,7 +1303,7 @@ void Engine::purge_cuts() {
     purged_total += m - m_new;
     stats["purges"] += 1.0;
     M = m_new; NNZ = nnz_new;
-    lp_dirty = true;
+    lp_dirty = true; ++lp_version;
 }
 
 void Engine::compute_scaling(bool identity) {
@@ -1829,7 +1833,11 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     auto tp = t0;
     if (lp_dirty) rebuild_csc();
     lap("lp_csc_time_s", tp);
-    compute_scaling(identity_scaling);
+    // (row-sharded: the versions are per rank while the scaling is a collective -- no reuse there)
+    static const bool no_reuse = std::getenv("KTN_NO_SETUP_REUSE") != nullptr;
+    const bool same_matrix = !no_reuse && !row_sharded() && scaled_version == lp_version && scaled_identity == identity_scaling;
+    if (!same_matrix) compute_scaling(identity_scaling);
+    else stats["lp_setup_reuses"] += 1.0;
     lap("lp_scaling_time_s", tp);
     const int64_t n = n_lp, m = M;
     const size_t mm = (size_t)std::max<int64_t>(m, 1);
@@ -1862,7 +1870,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn &&
                    NNZ >= 4096 * std::max(units_t, units_tt);
         if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0;
-        if (tiled_on) {
+        if (same_matrix) tiled_on = tiled_built;            // the copies of the previous solve (or their absence) still fit
+        else if (tiled_on) {
             auto tt = std::chrono::steady_clock::now();
             tiled_on = build_tiled(tA, M, n_lp, lp_rowptr.p, lp_col.p, r_sval.p, kLongRow) &&
                        build_tiled(tAT, n_lp, M, c_ptr.p, c_row.p, c_sval.p, (int64_t)1 << 62);
@@ -1871,6 +1880,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             stats["lp_tiled_build_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - tt).count();
             if (!tiled_on) stats["lp_tiled_overflows"] += 1.0;
         }
+        tiled_built = tiled_on;
+        scaled_version = lp_version; scaled_identity = identity_scaling;
     }
 
     // Step size eta = 0.998 / sigma_max(A^).  sigma_max comes from 8 power iterations (round 1: 20; hashed start
@@ -1887,7 +1898,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     static const double smax_reuse = std::getenv("KTN_SMAX_REUSE") ? std::atof(std::getenv("KTN_SMAX_REUSE")) : 0.0;
     const bool reuse_smax = mode == 0 && smax_reuse > 0.0 && smax_rows > 0 && m >= smax_rows && !row_sharded() &&
                             (double)(m - smax_rows) <= smax_reuse * (double)smax_rows && smax_prev > 0.0;
-    if (reuse_smax) { smax = smax_prev; stats["lp_smax_reused"] += 1.0; }
+    if (same_matrix && smax_version == lp_version && smax_prev > 0.0) smax = smax_prev;       // same matrix, same estimate
+    else if (reuse_smax) { smax = smax_prev; stats["lp_smax_reused"] += 1.0; }
     else if ((m > 0 && NNZ > 0) || row_sharded()) {
         // 8 passes from a hashed start vector (a looser estimate is a larger step: 20 -> 8 passes saves 6 % on cfg3 and 8 %
         // on cfg4 beyond the passes themselves; the back-off safeguards of the main loop catch an estimate that is too low).  Norms stay on the device (k_normalize reads them): one host
@@ -1943,7 +1955,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     if (have_power) {
         const double nv2 = hs[1];
         smax = (nv2 > 0.0) ? std::sqrt(std::sqrt(nv2)) : 0.0;     // sigma_max^2 ~ ||A'A v||
-        if (mode == 0) { smax_prev = smax; smax_rows = m; }
+        if (mode == 0) { smax_prev = smax; smax_rows = m; smax_version = lp_version; }
     }
     lap("lp_power_time_s", tp);
     double fro2 = (NNZ > 0) ? hs[2] : 0.0;                                              // ||A||_2 <= ||A||_F
@@ -2194,6 +2206,7 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
                       double* y_out) {
     if (lp_dirty) rebuild_csc();
     compute_scaling(true);
+    scaled_version = 0;                                  // (lp_solve_core must not take this identity scaling for its own)
     const int64_t n = n_lp, m = M;
     const size_t mm = (size_t)std::max<int64_t>(m, 1);
     ch.resize(n, stream); lh.resize(n, stream); uh.resize(n, stream); xh.resize(n, stream);
@@ -2768,7 +2781,7 @@ int ktn_lp_truncate(ktn_handle h, int64_t nrows) {
         e->lp_lo.n = e->lp_hi.n = e->lp_y.n = (size_t)nrows;
         if (e->d_age.n > (size_t)nrows) e->d_age.n = (size_t)nrows;
         if (e->d_cutprev.n > (size_t)nrows) e->d_cutprev.n = (size_t)nrows;
-        e->lp_dirty = true;
+        e->lp_dirty = true; ++e->lp_version;
         return KTN_OK;
     })
 }
@@ -2932,7 +2945,7 @@ int ktn_lp_append_rows_nl(ktn_handle h, int64_t nrows, const int64_t* rowptr, co
         e->sync();
         e->M += nrows; e->NNZ += nz; e->numcuts += nrows;
         e->sharded_rows = true;
-        e->lp_dirty = true;
+        e->lp_dirty = true; ++e->lp_version;
         return KTN_OK;
     })
 }
