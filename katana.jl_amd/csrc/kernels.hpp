@@ -1402,7 +1402,17 @@ __global__ __launch_bounds__(kTileThreads, 8) void k_spmv_tiled(int64_t n_out, i
 __device__ __forceinline__ double tile_pieces_sum(const double* __restrict__ part, int64_t o, int64_t n_out, const int32_t* __restrict__ pcnt) {
     const int np = pcnt[o / kTileOut];
     double acc = 0.0;
-    for (int p = 0; p < np; ++p) acc += part[(int64_t)p * n_out + o];
+    int p = 0;
+    // eight pieces requested before the first is added (the x-step has ~20 pieces per output and only 1.5 wavefronts per SIMD:
+    // one round trip per piece made the epilogue latency-bound); the additions keep the piece order
+    for (; p + 8 <= np; p += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = part[(int64_t)(p + k) * n_out + o];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    for (; p < np; ++p) acc += part[(int64_t)p * n_out + o];
     return acc;
 }
 // epilogues of the tiled steps: the pieces in order, then exactly the arithmetic of k_pdhg_x / k_pdhg_y
