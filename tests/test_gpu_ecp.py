@@ -325,3 +325,25 @@ def test_million_variable_instance_uses_the_csr_steps():
     assert m.stat("lp_tiled_builds") == 0
     assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
     assert max_nl_violation(inst, m.getsolution()[:inst.n]) <= 1e-6 * (1 + 1e-6)
+
+
+def test_residual_growth_backs_the_step_size_off():
+    """cfg3 seed 28: the 8-pass power iteration under-estimates sigma_max of every LP of this instance, the iteration is
+    expansive and the fixed-point residual grows check after check (r0 = 6 -> 87 -> 530 -> ... -> 2e5 without the guard, three
+    solves of 10 000 iterations each: 0.38 s).  The growth rule backs eta off within two checks: ~4 000 iterations in all"""
+    inst = ktn.instances.make_config("cfg3", seed=28)
+    m = hip_load_instance(ktn, inst)
+    assert m.optimize() == "Optimal"
+    assert m.stat("lp_divergence_backoffs") >= 1
+    assert m.stat("pdhg_iters") < 12000
+    assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
+
+
+def test_resolve_of_an_unchanged_lp_reuses_the_setup():
+    """the floor-tolerance re-solve after a loosely solved LP found every row satisfied works on the SAME matrix: scaling, tiled
+    copies and the sigma_max estimate are taken over (lp_setup_reuses), the answer is the planted optimum"""
+    inst = ktn.instances.make_config("cfg3", seed=0)
+    m = hip_load_instance(ktn, inst)
+    assert m.optimize() == "Optimal"
+    assert m.stat("lp_setup_reuses") >= 1
+    assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
