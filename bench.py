@@ -26,6 +26,8 @@ Prints ONE JSON line (rank 0).  `value` = ECP iterations / second, whole job.
                   (cfg3_hbm: 2048 instead of 32 entries per NL row, 411 MB per pass), same timing.
   spmv_roofline -- the LP SpMV steps on an HBM-resident cut matrix (cfg4's LP after one un-capped sweep: >= 1.2e7
                   non-zeros, CSR + CSC mirror beyond the Infinity Cache), same timing.
+  stream_ceiling -- torch.sum / copy_ over 1 GiB in the same run: the box's practical read and copy rates next to the 8 TB/s
+                  spec figure the fractions are quoted against.
   cpu_baseline -- the CPU oracle (serial restatement of the reference + HiGHS dual simplex, 1 core) on the SAME
                   configuration as `value` (full cfg3: one solve to f_tol, about 100 s of one host core).
 """
@@ -260,6 +262,27 @@ def main():
                 sweep_roofline["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction for 16-B/lane streams)"
         del sm, sep, hb
 
+    # The box's practical streaming ceilings next to the 8 TB/s spec figure `peak` ("quote the copy-kernel
+    # ceiling measured in the same run"): a read-only reduction and a copy over 1 GiB, plain torch kernels
+    stream_ceiling = None
+    if world == 1 and not args.no_roofline and rank == 0:
+        nel = (1 << 30) // 8
+        xs_ = torch.ones(nel, dtype=torch.float64, device="cuda")
+        ys_ = torch.empty_like(xs_)
+        stream_ceiling = {"unit": "GB/s", "working_set": "1 GiB f64 (beyond the 256 MiB Infinity Cache)", "kernels": "torch.sum / Tensor.copy_"}
+        for name, fn, nbytes in (("read", lambda: xs_.sum(), nel * 8), ("copy", lambda: ys_.copy_(xs_), 2 * nel * 8)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            stream_ceiling[name] = nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del xs_, ys_
+
     # The LP SpMV steps in the HBM regime (tools/spmv_bench.py): cfg4's LP after one un-capped sweep
     spmv_roofline = None
     if world == 1 and not args.no_roofline and not args.no_spmv_roofline and args.workload == "cfg3":
@@ -343,7 +366,8 @@ def main():
             "wall_to_ftol_s": wall_to_ftol, "ecp_iters_to_ftol": iters_to_ftol, "status": status, "objective": obj,
             "planted_objective": inst.opt_obj, "objective_relerr": abs(obj - inst.opt_obj) / max(1.0, abs(inst.opt_obj)),
             "pdhg_iters_per_step": pdhg_timed / args.steps, "solves_in_timed_region": len(solves),
-            "roofline": roofline, "sweep_roofline": sweep_roofline, "spmv_roofline": spmv_roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "sweep_roofline": sweep_roofline, "spmv_roofline": spmv_roofline, "stream_ceiling": stream_ceiling,
+            "cpu_baseline": cpu,
             "multi_gpu": multi,
         }
         print(json.dumps(out))
