@@ -211,6 +211,7 @@ class ShardedKatanaModel:
     def getsolvetime(self): return self.m.getsolvetime()
     def numiters(self): return self.iter
     def numcuts(self): return self.m.numcuts()
+    def lp_num_rows(self): return self.m.lp_num_rows()
     def stat(self, name): return self.m.stat(name)
 
 

@@ -409,3 +409,11 @@ def test_rccl_transport_with_one_rank_gives_the_single_gpu_answer():
     from helpers import planted_obj_bound
     assert abs(obj - inst.opt_obj) <= planted_obj_bound(inst) and abs(obj - one.getobjval()) <= planted_obj_bound(inst)
     assert np.max(np.abs(x - one.getsolution())) <= 1e-4
+
+
+def test_both_sharded_models_offer_what_bench_reads():
+    """bench.py's multi_gpu block reads these from whichever model `--replicated-lp` selects"""
+    from katana_jl_amd.distributed import RowShardedKatanaModel, ShardedKatanaModel
+    for cls in (ShardedKatanaModel, RowShardedKatanaModel):
+        for name in ("optimize", "getobjval", "getsolution", "numiters", "numcuts", "lp_num_rows", "stat", "status"):
+            assert callable(getattr(cls, name, None)), (cls.__name__, name)
