@@ -1246,11 +1246,12 @@ void Engine::purge_cuts() {
     d_age.resize((size_t)m, stream);
     d_keep.resize((size_t)m, stream); d_keepnnz.resize((size_t)m, stream);
     d_newidx.resize((size_t)m, stream); d_newptr.resize((size_t)m, stream);
-    LAUNCH_1(k_purge_mark, m, stream, M_base, m, lp_rowptr.p, lp_col.p, lp_val.p, lp_x.p, lp_lo.p, lp_hi.p, lp_y.p, d_age.p,
+    const int gp = pick_group((double)NNZ / (double)std::max<int64_t>(m, 1));      // lanes per row of the pool kernels
+    LAUNCH_G(gp, k_purge_mark, m, stream, M_base, m, lp_rowptr.p, lp_col.p, lp_val.p, lp_x.p, lp_lo.p, lp_hi.p, lp_y.p, d_age.p,
              prm.purge_margin, (int)prm.purge_age, d_keep.p, d_keepnnz.p);
     if (prm.dedupe_eps > 0.0 && lists_ok() && list_count() > 0) {
         KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
-        LAUNCH_1(k_dedupe_mark, list_count(), stream, list_count(), list_heads(), d_cutprev.p, lp_rowptr.p, lp_val.p, lp_lo.p, lp_hi.p, lp_y.p,
+        LAUNCH_G(gp, k_dedupe_mark, list_count(), stream, list_count(), list_heads(), d_cutprev.p, lp_rowptr.p, lp_val.p, lp_lo.p, lp_hi.p, lp_y.p,
                  prm.dedupe_eps, d_keep.p, d_keepnnz.p, d_anynf.p + 1);
         int32_t nd = 0;
         KTN_HIP(hipMemcpyAsync(&nd, d_anynf.p + 1, 4, hipMemcpyDeviceToHost, stream));
@@ -1273,7 +1274,7 @@ void Engine::purge_cuts() {
     lp_y2.resize((size_t)m_new, stream); d_age2.resize((size_t)m_new, stream); d_cutprev2.resize((size_t)m_new, stream);
     LpRows Old = lp_view();
     LpRows New{lp_rowptr2.p, lp_col2.p, lp_val2.p, lp_lo2.p, lp_hi2.p, lp_y2.p};
-    LAUNCH_1(k_purge_copy, m, stream, m, d_keep.p, d_newidx.p, d_newptr.p, Old, d_age.p, New, d_age2.p);
+    LAUNCH_G(gp, k_purge_copy, m, stream, m, d_keep.p, d_newidx.p, d_newptr.p, Old, d_age.p, New, d_age2.p);
     KTN_HIP(hipMemcpyAsync(lp_rowptr2.p + m_new, &nnz_new, 8, hipMemcpyHostToDevice, stream));
     if (lists_ok()) {
         LAUNCH_1(k_purge_relink, list_count(), stream, list_count(), list_heads(), d_cutprev.p, d_keep.p, d_newidx.p, d_cutprev2.p);

@@ -685,29 +685,33 @@ __global__ __launch_bounds__(kBlock) void k_consolidate(int64_t m_nl, const int6
 // no multiplier and is slack at x* for `max_age` consecutive LP solves is dropped: every cut is a valid
 // inequality of the convex feasible set, so dropping one keeps the LP an outer approximation, and the sweep
 // regenerates it should its row become violated again.
+// (G lanes per row in the three pool kernels below: a thread per row walked the 1e4-entry epigraph cuts of a nonlinear
+//  objective serially -- k_dedupe_mark 2.9 ms, k_purge_mark / k_purge_copy 1.3 ms per call on cfg2's QP variant)
+template <int G>
 __global__ __launch_bounds__(kBlock) void k_purge_mark(int64_t m_base, int64_t m, const int64_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ col, const double* __restrict__ val,
                                                        const double* __restrict__ x, const double* __restrict__ lo,
                                                        const double* __restrict__ hi, const double* __restrict__ y,
                                                        int32_t* __restrict__ age, double margin, int max_age,
                                                        int64_t* __restrict__ keep, int64_t* __restrict__ keepnnz) {
-    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t r = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
     if (r >= m) return;
-    const int64_t len = rowptr[r + 1] - rowptr[r];
+    const int64_t beg = rowptr[r], end = rowptr[r + 1], len = end - beg;
     bool k = true;
     if (r >= m_base) {
         double ax = 0.0;
-        for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) ax += val[e] * x[col[e]];
+        for (int64_t e = beg + lane; e < end; e += G) ax += val[e] * x[col[e]];
+        ax = group_sum<G>(ax);
         double slack = __builtin_inf(), scale = 1.0;
         if (isfinite(hi[r])) { slack = fmin(slack, hi[r] - ax); scale = fmax(scale, fabs(hi[r])); }
         if (isfinite(lo[r])) { slack = fmin(slack, ax - lo[r]); scale = fmax(scale, fabs(lo[r])); }
         const bool idle = (y[r] == 0.0) && (slack > margin * scale);
         const int a = idle ? age[r] + 1 : 0;
-        age[r] = a;
+        if (lane == 0) age[r] = a;
         k = a < max_age;
     }
-    keep[r] = k ? 1 : 0;
-    keepnnz[r] = k ? len : 0;
+    if (lane == 0) { keep[r] = k ? 1 : 0; keepnnz[r] = k ? len : 0; }
 }
 // Near-duplicate cuts (second half; the reference's TODO at src/model.jl:215).  Close to the
 // optimum successive iterates differ by ~1e-6, so successive tangent cuts of an active NL row are the same inequality up
@@ -715,19 +719,22 @@ __global__ __launch_bounds__(kBlock) void k_purge_mark(int64_t m_base, int64_t m
 // row the cuts older than its NEWEST one are compared with it after normalising by the largest coefficient: a cut whose
 // coefficients and bound agree within `eps` is dropped (dropping a cut only loosens the outer approximation, by O(eps)
 // here) and its multiplier moves to the newest cut.  One thread per NL slot walks the slot's list (deterministic).
+template <int G>
 __global__ __launch_bounds__(kBlock) void k_dedupe_mark(int64_t nslots, const int64_t* __restrict__ last_cut,
                                                         const int64_t* __restrict__ cut_prev, const int64_t* __restrict__ rowptr,
                                                         const double* __restrict__ val, const double* __restrict__ lo,
                                                         const double* __restrict__ hi, double* __restrict__ y, double eps,
                                                         int64_t* __restrict__ keep, int64_t* __restrict__ keepnnz,
                                                         int32_t* __restrict__ dropped) {
-    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t s = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
     if (s >= nslots) return;
     const int64_t head = last_cut[s];
     if (head < 0 || !keep[head]) return;
     const int64_t hb = rowptr[head], hl = rowptr[head + 1] - hb;
     double nh = 0.0;
-    for (int64_t e = 0; e < hl; ++e) nh = fmax(nh, fabs(val[hb + e]));
+    for (int64_t e = lane; e < hl; e += G) nh = fmax(nh, fabs(val[hb + e]));
+    nh = group_nanmax<G>(nh);                               // (every lane of the group takes the same branches below)
     if (!(nh > 0.0) || !isfinite(nh)) return;
     const bool up = isfinite(hi[head]);                     // a cut has one finite side (src/model.jl:74-75)
     const double bh = (up ? hi[head] : lo[head]) / nh;
@@ -738,31 +745,38 @@ __global__ __launch_bounds__(kBlock) void k_dedupe_mark(int64_t nslots, const in
         const int64_t rb = rowptr[r];
         if (rowptr[r + 1] - rb != hl || isfinite(hi[r]) != up) continue;
         double nr = 0.0;
-        for (int64_t e = 0; e < hl; ++e) nr = fmax(nr, fabs(val[rb + e]));
+        for (int64_t e = lane; e < hl; e += G) nr = fmax(nr, fabs(val[rb + e]));
+        nr = group_nanmax<G>(nr);
         if (!(nr > 0.0) || !isfinite(nr)) continue;
         const double br = (up ? hi[r] : lo[r]) / nr;
         if (!(fabs(br - bh) <= eps * (1.0 + fabs(bh)))) continue;
         double diff = 0.0;
-        for (int64_t e = 0; e < hl; ++e) diff = fmax(diff, fabs(val[rb + e] / nr - val[hb + e] / nh));
+        for (int64_t e = lane; e < hl; e += G) diff = nanmax(diff, fabs(val[rb + e] / nr - val[hb + e] / nh));
+        diff = group_nanmax<G>(diff);
         if (!(diff <= eps)) continue;
-        keep[r] = 0;
-        keepnnz[r] = 0;
-        y[head] += y[r] * (nr / nh);                        // A'y changes by O(eps |y|)
-        y[r] = 0.0;
+        if (lane == 0) {
+            keep[r] = 0; keepnnz[r] = 0;
+            y[head] += y[r] * (nr / nh);                    // A'y changes by O(eps |y|)
+            y[r] = 0.0;
+        }
         ++nd;
     }
-    if (nd) atomicAdd(dropped, nd);
+    if (lane == 0 && nd) atomicAdd(dropped, nd);
 }
+template <int G>
 __global__ __launch_bounds__(kBlock) void k_purge_copy(int64_t m, const int64_t* __restrict__ keep, const int64_t* __restrict__ newidx,
                                                        const int64_t* __restrict__ newptr, LpRows Old, const int32_t* __restrict__ age_old,
                                                        LpRows New, int32_t* __restrict__ age_new) {
-    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t r = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
     if (r >= m || !keep[r]) return;
     const int64_t nr = newidx[r], dst = newptr[r], src = Old.rowptr[r], len = Old.rowptr[r + 1] - src;
-    New.rowptr[nr] = dst;
-    for (int64_t e = 0; e < len; ++e) { New.col[dst + e] = Old.col[src + e]; New.val[dst + e] = Old.val[src + e]; }
-    New.lo[nr] = Old.lo[r]; New.hi[nr] = Old.hi[r]; New.y[nr] = Old.y[r];
-    age_new[nr] = age_old[r];
+    for (int64_t e = lane; e < len; e += G) { New.col[dst + e] = Old.col[src + e]; New.val[dst + e] = Old.val[src + e]; }
+    if (lane == 0) {
+        New.rowptr[nr] = dst;
+        New.lo[nr] = Old.lo[r]; New.hi[nr] = Old.hi[r]; New.y[nr] = Old.y[r];
+        age_new[nr] = age_old[r];
+    }
 }
 // re-thread the per-NL-row cut lists (k_consolidate) through the kept rows
 __global__ __launch_bounds__(kBlock) void k_purge_relink(int64_t m_nl, int64_t* __restrict__ last_cut,
