@@ -1625,9 +1625,24 @@ void Engine::launch_y(const SpMat& A, double sigma, double w, double rho, hipEve
                               loh.p, hih.p, sigma, w, rho);
     } else if (packed_on) {
         const int thr32 = n_long > 0 ? (int)kLongRow : 0x7fffffff;
-        if (packed_trips == 2) LAUNCH_GT(grp_rows, 2, k_pdhg_y_packed, m, stream, e0, e1, m, A.idx, A.val, xbar.p, yh.p, d_rrec.p, sigma, w, rho, thr32);
-        else if (packed_trips == 4) LAUNCH_GT(grp_rows, 4, k_pdhg_y_packed, m, stream, e0, e1, m, A.idx, A.val, xbar.p, yh.p, d_rrec.p, sigma, w, rho, thr32);
-        else LAUNCH_GT(grp_rows, 1, k_pdhg_y_packed, m, stream, e0, e1, m, A.idx, A.val, xbar.p, yh.p, d_rrec.p, sigma, w, rho, thr32);
+        const int32_t* none = nullptr;
+        if (packed_trips == 2) LAUNCH_GT(grp_rows, 2, k_pdhg_y_packed, m, stream, e0, e1, m, A.idx, A.val, xbar.p, yh.p, d_rrec.p, sigma, w, rho, thr32, none, 0);
+        else if (packed_trips == 4) LAUNCH_GT(grp_rows, 4, k_pdhg_y_packed, m, stream, e0, e1, m, A.idx, A.val, xbar.p, yh.p, d_rrec.p, sigma, w, rho, thr32, none, 0);
+        else {
+            // one launch for all rows: the regular lane groups plus one trailing workgroup per long row
+            const unsigned grid = (unsigned)(ceil_div(m * grp_rows, (int64_t)kBlock) + n_long);
+#define KTN_Y_PACKED(G) hipExtLaunchKernelGGL((k_pdhg_y_packed<G, 1>), dim3(grid), dim3(kBlock), 0, stream, e0, e1, 0, m, A.idx, A.val, xbar.p, yh.p, \
+                                              d_rrec.p, sigma, w, rho, thr32, (const int32_t*)d_longrows.p, (int)n_long)
+            switch (grp_rows) {
+                case 4: KTN_Y_PACKED(4); break;
+                case 8: KTN_Y_PACKED(8); break;
+                case 16: KTN_Y_PACKED(16); break;
+                case 32: KTN_Y_PACKED(32); break;
+                default: KTN_Y_PACKED(64); break;
+            }
+#undef KTN_Y_PACKED
+            return;
+        }
     } else if (e0) {
         LAUNCH_G_EV(grp_rows, k_pdhg_y, m, stream, e0, e1, m, A, xbar.p, yh.p, y0h.p, loh.p, hih.p, sigma, w, rho, thr);
     } else {

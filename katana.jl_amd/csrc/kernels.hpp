@@ -963,8 +963,43 @@ template <int G, int T>
 __global__ __launch_bounds__(kBlock) void k_pdhg_y_packed(int64_t m, const int32_t* __restrict__ idx, const double* __restrict__ val,
                                                           const double* __restrict__ xbar, double* __restrict__ y,
                                                           const RowRec* __restrict__ rec, double sigma, double w, double rho,
-                                                          int long_thresh) {
-    const int64_t groups = (int64_t)gridDim.x * (kBlock / G);
+                                                          int long_thresh, const int32_t* __restrict__ long_rows, int n_long) {
+    // The last n_long workgroups of the grid take one LONG row each (dense epigraph cuts: n + 1 entries) -- the rows the lane
+    // groups below skip.  They used to be a launch of their own (k_pdhg_y_long): 6 us + a boundary per PDHG iteration, a
+    // quarter of the GPU time of cfg2's QP variant.  Eight entries per thread are requested before the first is used;
+    // fixed-shape reduction (butterfly per wavefront, wavefronts in order) => deterministic.
+    const int nreg = (int)gridDim.x - n_long;
+    if ((int)blockIdx.x >= nreg) {
+        __shared__ double sh[kBlock / 64];
+        const int i = long_rows[(int)blockIdx.x - nreg];
+        const RowRec rr = rec[i];
+        const int end = rr.beg + rr.len;
+        double acc = 0.0;
+        int e = rr.beg + (int)threadIdx.x;
+        for (; e + 7 * kBlock < end; e += 8 * kBlock) {
+            double v[8], xg[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = val[e + k * kBlock];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xg[k] = xbar[idx[e + k * kBlock]];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k] * xg[k];
+        }
+        for (; e < end; e += kBlock) acc += val[e] * xbar[idx[e]];
+        acc = group_sum<64>(acc);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0;
+            for (int k = 0; k < kBlock / 64; ++k) a += sh[k];
+            const double yv = y[i];
+            const double v = yv - sigma * a;
+            const double ytv = v + sigma * clampd(-v / sigma, rr.lo, rr.hi);
+            y[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * rr.y0;
+        }
+        return;
+    }
+    const int64_t groups = (int64_t)nreg * (kBlock / G);
     const int64_t g0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     RowRec r[T];
