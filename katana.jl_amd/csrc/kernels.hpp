@@ -966,7 +966,7 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_y_packed(int64_t m, const int32
                                                           int long_thresh, const int32_t* __restrict__ long_rows, int n_long) {
     // The last n_long workgroups of the grid take one LONG row each (dense epigraph cuts: n + 1 entries) -- the rows the lane
     // groups below skip.  They used to be a launch of their own (k_pdhg_y_long): 6 us + a boundary per PDHG iteration, a
-    // quarter of the GPU time of cfg2's QP variant.  Eight entries per thread are requested before the first is used;
+    // quarter of the GPU time of cfg2's QP variant.  Sixteen entries per thread are requested before the first is used;
     // fixed-shape reduction (butterfly per wavefront, wavefronts in order) => deterministic.
     const int nreg = (int)gridDim.x - n_long;
     if ((int)blockIdx.x >= nreg) {
@@ -976,14 +976,23 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_y_packed(int64_t m, const int32
         const int end = rr.beg + rr.len;
         double acc = 0.0;
         int e = rr.beg + (int)threadIdx.x;
-        for (; e + 7 * kBlock < end; e += 8 * kBlock) {
-            double v[8], xg[8];
+        for (; e + 15 * kBlock < end; e += 16 * kBlock) {
+            double v[16], xg[16];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = val[e + k * kBlock];
+            for (int k = 0; k < 16; ++k) v[k] = val[e + k * kBlock];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) xg[k] = xbar[idx[e + k * kBlock]];
+            for (int k = 0; k < 16; ++k) xg[k] = xbar[idx[e + k * kBlock]];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc += v[k] * xg[k];
+            for (int k = 0; k < 16; ++k) acc += v[k] * xg[k];
+        }
+        for (; e + 3 * kBlock < end; e += 4 * kBlock) {
+            double v[4], xg[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = val[e + k * kBlock];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xg[k] = xbar[idx[e + k * kBlock]];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc += v[k] * xg[k];
         }
         for (; e < end; e += kBlock) acc += val[e] * xbar[idx[e]];
         acc = group_sum<64>(acc);
