@@ -1874,8 +1874,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     SpMat A{lp_rowptr.p, lp_col.p, r_sval.p};
     SpMat AT{c_ptr.p, c_row.p, c_sval.p};
     find_long_rows();
-    // LPs beyond the caches: tiled copies of A^ and A^' (kernels.hpp "tiled SpMV"); the check iterations (1 in 64) and the
-    // power iteration keep the CSR / CSC kernels
+    // LPs beyond the caches: tiled copies of A^ and A^' (kernels.hpp "tiled SpMV") serve the plain steps and the check
+    // iterations; the power iteration keeps the CSR / CSC kernels
     {
         static const char* tenv = std::getenv("KTN_TILED");
         // ... and dense enough: every (tile, block) unit stages a 64 KB block of the input vector, so a matrix with few entries
@@ -2241,8 +2241,8 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
     KTN_HIP(hipMemcpyAsync(x0h.p, xh.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     if (m > 0) KTN_HIP(hipMemcpyAsync(y0h.p, yh.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
     find_long_rows();
-    // LPs beyond the caches: tiled copies of A^ and A^' (kernels.hpp "tiled SpMV"); the check iterations (1 in 64) and the
-    // power iteration keep the CSR / CSC kernels
+    // LPs beyond the caches: tiled copies of A^ and A^' (kernels.hpp "tiled SpMV") serve the plain steps and the check
+    // iterations; the power iteration keeps the CSR / CSC kernels
     {
         static const char* tenv = std::getenv("KTN_TILED");
         // ... and dense enough: every (tile, block) unit stages a 64 KB block of the input vector, so a matrix with few entries
