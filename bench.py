@@ -26,6 +26,8 @@ Prints ONE JSON line (rank 0).  `value` = ECP iterations / second, whole job.
                   (cfg3_hbm: 2048 instead of 32 entries per NL row, 411 MB per pass), same timing.
   spmv_roofline -- the LP SpMV steps on an HBM-resident cut matrix (cfg4's LP after one un-capped sweep: >= 1.2e7
                   non-zeros, CSR + CSC mirror beyond the Infinity Cache), same timing.
+  --workload cfg5 -- BASELINE.json configs[4] instead: the batch of 512 independent instances in throughput mode, split into one
+                  contiguous block per GPU with no communication; `value` is then instances/s (its own `metric` string).
   stream_ceiling -- torch.sum / copy_ over 1 GiB in the same run: the box's practical read and copy rates next to the 8 TB/s
                   spec figure the fractions are quoted against.
   cpu_baseline -- the CPU oracle (serial restatement of the reference + HiGHS dual simplex, 1 core) on the SAME
@@ -123,6 +125,56 @@ def cpu_baseline(args):
     }
 
 
+def main_batch(args, ktn, torch, dist, rank, world, local_rank, backend):
+    """--workload cfg5: BASELINE.json configs[4], the batch of 512 independent 1e3-variable instances in throughput mode.  A
+    step is one solve of the whole batch (instance fusion + load + the device-side loop + read-back); with N > 1 ranks the
+    batch is split into N contiguous blocks, one per GPU, with no communication on the data path (SURVEY.md section 8e
+    "replicas only").  `value` = instances solved per second by the whole job."""
+    nb = 512
+    insts = [ktn.instances.make_config("cfg5_one", seed=s) for s in range(nb)]
+    from katana_jl_amd.batch import shard_range, solve_batch_sharded
+    lo, hi = shard_range(nb, rank, world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_pass():
+        return solve_batch_sharded(ktn.KatanaSolver(log_level=0, device=local_rank), insts, rank, world, None, gather=False)
+
+    for _ in range(args.warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    ok = True
+    worst = 0.0
+    for _ in range(args.steps):
+        res, _ = one_pass()
+        for r, inst in zip(res, insts[lo:hi]):
+            ok = ok and r["status"] == "Optimal"
+            worst = max(worst, abs(r["objval"] - inst.opt_obj) / max(1.0, abs(inst.opt_obj)))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    flags = torch.tensor([elapsed, 0.0 if ok else 1.0, worst], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    if dist is not None:
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    elapsed, bad, worst = (float(v) for v in flags.tolist())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "instances/s, batch of 512 independent 1e3-var convex NLPs to f_tol=1e-6 (throughput mode, BASELINE.json configs[4])",
+            "value": nb * args.steps / elapsed, "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg5: 512 x (n=1000 variables, m_lin=500 linear rows, m_nl=100 explog rows, k=16), seeds 0..511, "
+                                   "planted optima; one fused batch per GPU, every instance's loop in its own workgroup",
+                       "parallelism": "1 GPU" if world == 1 else "%d contiguous blocks of the batch, one per GPU, no communication" % world},
+            "status": "Optimal" if bad == 0.0 else "some instance not Optimal", "max_objective_relerr": worst,
+            "roofline": None, "cpu_baseline": None}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     import torch
@@ -147,6 +199,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.workload == "cfg5":
+        return main_batch(args, ktn, torch, dist, rank, world, local_rank, backend)
     inst = ktn.instances.make_config(args.workload, seed=args.seed)
     if world > 1 and args.replicated_lp:
         from katana_jl_amd.distributed import ShardedKatanaModel

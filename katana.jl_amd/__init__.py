@@ -20,8 +20,8 @@ from .solver import (KatanaSolver, KatanaNonlinearModel, KatanaHipSeparator, Non
                      getKatanaModel, getKatanaCuts, getKatanaSols, STATUS_SYMBOLS)
 from .jump_like import Model
 from . import instances
-from .batch import solve_batch
+from .batch import solve_batch, solve_batch_sharded
 
 __all__ = ["KatanaSolver", "KatanaNonlinearModel", "KatanaHipSeparator", "NonlinearModel", "getKatanaModel",
            "getKatanaCuts", "getKatanaSols", "NLPDescription", "SeparableNLP", "ExprNLP", "CallbackNLP", "Model", "Expr", "var",
-           "const", "exp", "log", "sqrt", "sin", "cos", "from_sexpr", "instances", "STATUS_SYMBOLS", "solve_batch"]
+           "const", "exp", "log", "sqrt", "sin", "cos", "from_sexpr", "instances", "STATUS_SYMBOLS", "solve_batch", "solve_batch_sharded"]

@@ -71,3 +71,25 @@ def _solve_fused(solver, instances, per_instance_lp=False, device_loop=False):
                   ecp_blocks_fallbacks=m.stat("ecp_blocks_fallbacks"), ecp_blocks_pdhg_sum=m.stat("ecp_blocks_pdhg_sum"))
     out = [dict(common, objval=float(seg[k] + inst.obj_const), x=x[offs[k]:offs[k + 1]]) for k, inst in enumerate(instances)]
     return out, time.perf_counter() - t0
+
+
+def shard_range(count, rank, world):
+    """contiguous block of `count` items owned by `rank` (sizes differ by at most one)"""
+    return (count * rank) // world, (count * (rank + 1)) // world
+
+
+def solve_batch_sharded(solver, instances, rank, world, dist=None, gather=True, **kw):
+    """Throughput mode over several GPUs (SURVEY.md section 8e "batch mode: replicas only, no communication"): rank r solves
+    the contiguous block shard_range(len(instances), r, world) of the batch on ITS device as one fused batch (solve_batch,
+    fused=True by default: every instance's loop inside its own workgroup).  The data path has no collective.  With
+    gather=True the per-instance results are exchanged afterwards through `dist.all_gather_object` (host objects: statuses,
+    objectives, solutions) so that every rank returns the results of the whole batch, in the order of `instances`; with
+    gather=False a rank returns only its own block.  Returns (results, wall_seconds of this rank's solve)."""
+    lo, hi = shard_range(len(instances), rank, world)
+    kw.setdefault("fused", True)
+    mine, wall = solve_batch(solver, instances[lo:hi], **kw) if hi > lo else ([], 0.0)
+    if not gather or dist is None or world == 1:
+        return mine, wall
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    return [r for part in parts for r in part], wall

@@ -417,3 +417,44 @@ def test_both_sharded_models_offer_what_bench_reads():
     for cls in (ShardedKatanaModel, RowShardedKatanaModel):
         for name in ("optimize", "getobjval", "getsolution", "numiters", "numcuts", "lp_num_rows", "stat", "status"):
             assert callable(getattr(cls, name, None)) or hasattr(cls, "__getattr__"), (cls.__name__, name)     # (the row-sharded model forwards to its handle)
+
+
+def _worker_batch_sharded(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import katana_jl_amd as ktn
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    insts = [ktn.instances.make_instance(n=300, m_nl=30, k=8, family="explog", seed=100 + s) for s in range(13)]
+    res, _ = ktn.solve_batch_sharded(ktn.KatanaSolver(log_level=0, device=0), insts, rank, world, dist)
+    own, _ = ktn.solve_batch_sharded(ktn.KatanaSolver(log_level=0, device=0), insts, rank, world, dist, gather=False)
+    out[rank] = ([(r["status"], r["objval"]) for r in res], len(own))
+    dist.destroy_process_group()
+
+
+def test_batch_blocks_partition_the_batch():
+    from katana_jl_amd.batch import shard_range
+    for count in (0, 1, 13, 512):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_range(count, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == count
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            assert max(b[1] - b[0] for b in blocks) - min(b[1] - b[0] for b in blocks) <= 1
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_batch_equals_the_single_gpu_batch():
+    """throughput mode over 2 ranks (replicas only): every rank solves its contiguous block of the batch
+    as one fused batch; gathered, the results are those of the whole batch solved on one GPU, instance by instance"""
+    import katana_jl_amd as ktn
+    from helpers import planted_obj_bound
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker_batch_sharded, args=(world, _free_port(), out), nprocs=world, join=True)
+    insts = [ktn.instances.make_instance(n=300, m_nl=30, k=8, family="explog", seed=100 + s) for s in range(13)]
+    one, _ = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts, fused=True)
+    assert out[0][0] == out[1][0] and len(out[0][0]) == 13
+    assert out[0][1] + out[1][1] == 13 and abs(out[0][1] - out[1][1]) <= 1
+    for (st, obj), ref, inst in zip(out[0][0], one, insts):
+        assert st == ref["status"] == "Optimal"
+        assert abs(obj - ref["objval"]) <= planted_obj_bound(inst)             # the same answer up to the stop rule
+        assert abs(obj - inst.opt_obj) <= planted_obj_bound(inst)
