@@ -347,3 +347,16 @@ def test_resolve_of_an_unchanged_lp_reuses_the_setup():
     assert m.optimize() == "Optimal"
     assert m.stat("lp_setup_reuses") >= 1
     assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
+
+
+def test_fused_batch_solves_again_from_the_loaded_state():
+    """FusedBatch: the batch is loaded once; every further solve() starts from the loaded state (ktn_reset) with the data
+    resident -- the same answers, bit for bit, as the first (what bench.py --workload cfg5 times)"""
+    from katana_jl_amd.batch import FusedBatch
+    insts = [ktn.instances.make_instance(n=300, m_nl=30, k=8, family="explog", seed=40 + s) for s in range(8)]
+    fb = FusedBatch(ktn.KatanaSolver(log_level=0), insts)
+    first, again = fb.solve(), fb.solve()
+    for a, b, inst in zip(first, again, insts):
+        assert a["status"] == b["status"] == "Optimal"
+        assert a["objval"] == b["objval"] and np.array_equal(a["x"], b["x"])
+        assert abs(a["objval"] - inst.opt_obj) <= planted_obj_bound(inst)
