@@ -162,7 +162,7 @@ def main_batch(args, ktn, torch, dist, rank, world, local_rank, backend):
     barrier()
     t1 = time.perf_counter()
     for _ in range(3):
-        if mine: FusedBatch(ktn.KatanaSolver(log_level=0, device=local_rank), mine).solve()
+        if fb: fb.load(mine).solve()                  # (a serving process keeps its handle: FusedBatch.load)
     barrier()
     incl = (time.perf_counter() - t1) / 3
     flags = torch.tensor([elapsed, 0.0 if ok else 1.0, worst, incl, load_s], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -180,7 +180,7 @@ def main_batch(args, ktn, torch, dist, rank, world, local_rank, backend):
                        "parallelism": "1 GPU" if world == 1 else "%d contiguous blocks of the batch, one per GPU, no communication" % world},
             "status": "Optimal" if bad == 0.0 else "some instance not Optimal", "max_objective_relerr": worst,
             "incl_load": {"instances_per_s": nb / incl, "s_per_batch": incl, "first_load_s": load_s,
-                          "what": "instance fusion + row-program description + ktn_loadproblem + ktn_set_blocks + solve, per batch"},
+                          "what": "instance fusion + row-program description + ktn_loadproblem + ktn_set_blocks on the same handle + solve, per batch"},
             "roofline": None, "cpu_baseline": None}))
     if dist is not None:
         dist.destroy_process_group()

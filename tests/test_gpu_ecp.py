@@ -360,3 +360,19 @@ def test_fused_batch_solves_again_from_the_loaded_state():
         assert a["status"] == b["status"] == "Optimal"
         assert a["objval"] == b["objval"] and np.array_equal(a["x"], b["x"])
         assert abs(a["objval"] - inst.opt_obj) <= planted_obj_bound(inst)
+
+
+def test_fused_batch_reloads_another_batch_on_the_same_handle():
+    """FusedBatch.load: a second, different batch on the handle that solved the first -- the answers of a fresh handle"""
+    from katana_jl_amd.batch import FusedBatch
+    a = [ktn.instances.make_instance(n=300, m_nl=30, k=8, family="explog", seed=60 + s) for s in range(6)]
+    b = [ktn.instances.make_instance(n=300, m_nl=30, k=8, family="quad", seed=70 + s) for s in range(9)]
+    fb = FusedBatch(ktn.KatanaSolver(log_level=0), a)
+    fb.solve()
+    got = fb.load(b).solve()
+    ref = FusedBatch(ktn.KatanaSolver(log_level=0), b).solve()
+    assert len(got) == 9
+    for g, r, inst in zip(got, ref, b):
+        assert g["status"] == r["status"] == "Optimal"
+        assert g["objval"] == r["objval"] and np.array_equal(g["x"], r["x"])
+        assert abs(g["objval"] - inst.opt_obj) <= planted_obj_bound(inst)
