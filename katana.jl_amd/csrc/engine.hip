@@ -1339,7 +1339,13 @@ void Engine::compute_scaling(bool identity) {
                 KTN_HIP(hipMemcpyAsync(dr_r.p, dr.p, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, stream));
                 KTN_HIP(hipMemcpyAsync(dc_r.p, dc.p, (size_t)n_lp * sizeof(double), hipMemcpyDeviceToDevice, stream));
             }
-            LAUNCH_G(gr, k_scale_stat, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, mode, statr.p);
+            if (n_long > 0) {
+                LAUNCH_G(gr, k_scale_stat_skip, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, mode, statr.p, kLongRow);
+                hipLaunchKernelGGL(k_scale_stat_long, dim3((unsigned)n_long), dim3(1024), 0, stream, d_longrows.p, lp_rowptr.p, lp_col.p,
+                                   lp_val.p, dr.p, dc.p, mode, statr.p);
+            } else {
+                LAUNCH_G(gr, k_scale_stat, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, mode, statr.p);
+            }
             LAUNCH_G(gc, k_scale_stat, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, statc.p);
             if (row_sharded()) {                       // a column's max / sum runs over the rows of every rank
                 if (M == 0) LAUNCH_1(k_fill, n_lp, stream, n_lp, statc.p, 0.0);
@@ -1852,6 +1858,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     // (row-sharded: the versions are per rank while the scaling is a collective -- no reuse there)
     static const bool no_reuse = std::getenv("KTN_NO_SETUP_REUSE") != nullptr;
     const bool same_matrix = !no_reuse && !row_sharded() && scaled_version == lp_version && scaled_identity == identity_scaling;
+    find_long_rows();                                   // (before the scaling: its row passes treat long rows separately)
     if (!same_matrix) compute_scaling(identity_scaling);
     else stats["lp_setup_reuses"] += 1.0;
     lap("lp_scaling_time_s", tp);
@@ -1873,7 +1880,6 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     if (const char* g = std::getenv("KTN_GRP_COLS")) grp_cols = std::atoi(g);
     SpMat A{lp_rowptr.p, lp_col.p, r_sval.p};
     SpMat AT{c_ptr.p, c_row.p, c_sval.p};
-    find_long_rows();
     // LPs beyond the caches: tiled copies of A^ and A^' (kernels.hpp "tiled SpMV") serve the plain steps and the check
     // iterations; the power iteration keeps the CSR / CSC kernels
     {
@@ -1939,7 +1945,12 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         // estimate): with ||A^||_2 <= 1 after the Pock-Chambolle pass the un-normalised vector only shrinks slowly, and the
         // Rayleigh quotient does not depend on the scale -- 6 instead of 20 (dot, final sum, normalise) triples per LP solve.
         for (int it = 0; it < iters; ++it) {
-            LAUNCH_G(grp_rows, k_spmv, m, stream, m, A, pv.p, pw.p);
+            if (n_long > 0) {
+                LAUNCH_G(grp_rows, k_spmv_skip, m, stream, m, A, pv.p, pw.p, kLongRow);
+                hipLaunchKernelGGL(k_spmv_long, dim3((unsigned)n_long), dim3(1024), 0, stream, d_longrows.p, A, pv.p, pw.p);
+            } else {
+                LAUNCH_G(grp_rows, k_spmv, m, stream, m, A, pv.p, pw.p);
+            }
             const bool norm_now = (it % 4 == 3) || it >= iters - 2;
             if (norm_now) {
                 LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, pw.p, xbar.p);

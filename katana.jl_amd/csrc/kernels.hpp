@@ -1629,6 +1629,45 @@ __global__ __launch_bounds__(kBlock) void k_scale_stat(int64_t m, const int64_t*
     acc = mode ? group_sum<G>(acc) : group_max<G>(acc);
     if (lane == 0) out[i] = dself[i] * acc;
 }
+// the same with the long rows left to k_scale_stat_long (one 1024-thread workgroup per long row)
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_scale_stat_skip(int64_t m, const int64_t* __restrict__ ptr,
+                                                            const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                            const double* __restrict__ dself, const double* __restrict__ dother,
+                                                            int mode, double* __restrict__ out, int64_t skip_longer) {
+    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (i >= m) return;
+    const int64_t beg = ptr[i], end = ptr[i + 1];
+    if (end - beg > skip_longer) return;
+    double acc = 0.0;
+    for (int64_t e = beg + lane; e < end; e += G) {
+        const double v = fabs(val[e]) * dother[idx[e]];
+        acc = mode ? acc + v : fmax(acc, v);
+    }
+    acc = mode ? group_sum<G>(acc) : group_max<G>(acc);
+    if (lane == 0) out[i] = dself[i] * acc;
+}
+__global__ __launch_bounds__(1024) void k_scale_stat_long(const int32_t* __restrict__ rows, const int64_t* __restrict__ ptr,
+                                                          const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                          const double* __restrict__ dself, const double* __restrict__ dother,
+                                                          int mode, double* __restrict__ out) {
+    __shared__ double sh[1024 / 64];
+    const int64_t i = rows[blockIdx.x];
+    double acc = 0.0;
+    for (int64_t e = ptr[i] + threadIdx.x; e < ptr[i + 1]; e += 1024) {
+        const double v = fabs(val[e]) * dother[idx[e]];
+        acc = mode ? acc + v : fmax(acc, v);
+    }
+    acc = mode ? group_sum<64>(acc) : group_max<64>(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int k = 0; k < 1024 / 64; ++k) a = mode ? a + sh[k] : fmax(a, sh[k]);
+        out[i] = dself[i] * a;
+    }
+}
 __global__ __launch_bounds__(kBlock) void k_scale_apply(int64_t m, double* __restrict__ d, const double* __restrict__ stat) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
@@ -1724,6 +1763,36 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int64_t m, SpMat A, const doubl
     for (int64_t e = A.ptr[i] + lane; e < A.ptr[i + 1]; e += G) acc += A.val[e] * v[A.idx[e]];
     acc = group_sum<G>(acc);
     if (lane == 0) out[i] = acc;
+}
+// Row-side products of a matrix with a few LONG rows (dense epigraph cuts): the lane groups skip them and one 1024-thread
+// workgroup per long row does them (k_spmv_long) -- a 1e4-entry row given to a 32-lane group made the whole launch wait 60 us.
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_spmv_skip(int64_t m, SpMat A, const double* __restrict__ v, double* __restrict__ out,
+                                                      int64_t skip_longer) {
+    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (i >= m) return;
+    const int64_t beg = A.ptr[i], end = A.ptr[i + 1];
+    if (end - beg > skip_longer) return;
+    double acc = 0.0;
+    for (int64_t e = beg + lane; e < end; e += G) acc += A.val[e] * v[A.idx[e]];
+    acc = group_sum<G>(acc);
+    if (lane == 0) out[i] = acc;
+}
+__global__ __launch_bounds__(1024) void k_spmv_long(const int32_t* __restrict__ rows, SpMat A, const double* __restrict__ v,
+                                                    double* __restrict__ out) {
+    __shared__ double sh[1024 / 64];
+    const int64_t i = rows[blockIdx.x];
+    double acc = 0.0;
+    for (int64_t e = A.ptr[i] + threadIdx.x; e < A.ptr[i + 1]; e += 1024) acc += A.val[e] * v[A.idx[e]];
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int k = 0; k < 1024 / 64; ++k) a += sh[k];
+        out[i] = a;
+    }
 }
 // partials[b] = sum over the block's grid-stride share of a_i * b_i  (b may alias a)
 __global__ __launch_bounds__(kBlock) void k_dot_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
