@@ -364,7 +364,7 @@ struct Engine {
         partials.resize((size_t)kRedBlocks * kChkQ * 2, stream);
         chkout.resize(kChkQ * 2 + 8, stream);
         if (std::getenv("KTN_NO_PINNED_CHECK") == nullptr &&
-            hipHostMalloc((void**)&h_chk, sizeof(double) * 2 * kChkQ, hipHostMallocMapped) == hipSuccess) {
+            hipHostMalloc((void**)&h_chk, sizeof(double) * (2 * kChkQ + 16), hipHostMallocMapped) == hipSuccess) {
             if (hipHostGetDevicePointer((void**)&h_chk_dev, h_chk, 0) != hipSuccess) { (void)hipHostFree(h_chk); h_chk = nullptr; h_chk_dev = nullptr; }
         } else {
             h_chk = nullptr;
@@ -579,13 +579,23 @@ struct Engine {
         int64_t tail[4];
         double mv = 0.0;
         int32_t anynf = 0;
-        KTN_HIP(hipMemcpyAsync(&tail[0], d_flag.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
-        KTN_HIP(hipMemcpyAsync(&tail[1], d_rank.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
-        KTN_HIP(hipMemcpyAsync(&tail[2], d_cnt.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
-        KTN_HIP(hipMemcpyAsync(&tail[3], d_cntscan.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
-        KTN_HIP(hipMemcpyAsync(&mv, d_scal.p, 8, hipMemcpyDeviceToHost, stream));
-        KTN_HIP(hipMemcpyAsync(&anynf, d_anynf.p, 4, hipMemcpyDeviceToHost, stream));
-        sync();
+        if (h_chk_dev) {                               // one thread gathers the six scalars into pinned host memory
+            double* ht = h_chk + 2 * kChkQ;
+            hipLaunchKernelGGL(k_host_tail, dim3(1), dim3(1), 0, stream, h_chk_dev + 2 * kChkQ, d_flag.p + (m_nl - 1), d_rank.p + (m_nl - 1),
+                               d_cnt.p + (m_nl - 1), d_cntscan.p + (m_nl - 1), (const double*)d_scal.p, (const int32_t*)d_anynf.p,
+                               (const int32_t*)nullptr);
+            sync();
+            for (int k = 0; k < 4; ++k) tail[k] = (int64_t)ht[k];
+            mv = ht[4]; anynf = (int32_t)ht[5];
+        } else {
+            KTN_HIP(hipMemcpyAsync(&tail[0], d_flag.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
+            KTN_HIP(hipMemcpyAsync(&tail[1], d_rank.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
+            KTN_HIP(hipMemcpyAsync(&tail[2], d_cnt.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
+            KTN_HIP(hipMemcpyAsync(&tail[3], d_cntscan.p + (m_nl - 1), 8, hipMemcpyDeviceToHost, stream));
+            KTN_HIP(hipMemcpyAsync(&mv, d_scal.p, 8, hipMemcpyDeviceToHost, stream));
+            KTN_HIP(hipMemcpyAsync(&anynf, d_anynf.p, 4, hipMemcpyDeviceToHost, stream));
+            sync();
+        }
         if (prm.profile) ev_flush();
         int64_t V = tail[0] + tail[1], nnzV = tail[2] + tail[3];
         *nviol_out = V;                // the stop rule counts EVERY violated row (model.jl:273-283)
@@ -1263,24 +1273,35 @@ void Engine::purge_cuts() {
     const int gp = pick_group((double)NNZ / (double)std::max<int64_t>(m, 1));      // lanes per row of the pool kernels
     LAUNCH_G(gp, k_purge_mark, m, stream, M_base, m, lp_rowptr.p, lp_col.p, lp_val.p, lp_x.p, lp_lo.p, lp_hi.p, lp_y.p, d_age.p,
              prm.purge_margin, (int)prm.purge_age, d_keep.p, d_keepnnz.p);
+    bool deduped = false;
     if (prm.dedupe_eps > 0.0 && lists_ok() && list_count() > 0) {
         KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
         LAUNCH_G(gp, k_dedupe_mark, list_count(), stream, list_count(), list_heads(), d_cutprev.p, lp_rowptr.p, lp_val.p, lp_lo.p, lp_hi.p, lp_y.p,
                  prm.dedupe_eps, d_keep.p, d_keepnnz.p, d_anynf.p + 1);
-        int32_t nd = 0;
-        KTN_HIP(hipMemcpyAsync(&nd, d_anynf.p + 1, 4, hipMemcpyDeviceToHost, stream));
-        sync();
-        stats["deduped_rows"] += (double)nd;
+        deduped = true;
     }
     check_launch();
     exclusive_scan(d_keep.p, d_newidx.p, (size_t)m);
     exclusive_scan(d_keepnnz.p, d_newptr.p, (size_t)m);
     int64_t t[4];
-    KTN_HIP(hipMemcpyAsync(&t[0], d_keep.p + (m - 1), 8, hipMemcpyDeviceToHost, stream));
-    KTN_HIP(hipMemcpyAsync(&t[1], d_newidx.p + (m - 1), 8, hipMemcpyDeviceToHost, stream));
-    KTN_HIP(hipMemcpyAsync(&t[2], d_keepnnz.p + (m - 1), 8, hipMemcpyDeviceToHost, stream));
-    KTN_HIP(hipMemcpyAsync(&t[3], d_newptr.p + (m - 1), 8, hipMemcpyDeviceToHost, stream));
-    sync();
+    int32_t nd = 0;
+    if (h_chk_dev) {                                   // the four scan tails and the dedupe count in one round trip
+        double* ht = h_chk + 2 * kChkQ + 8;
+        hipLaunchKernelGGL(k_host_tail, dim3(1), dim3(1), 0, stream, h_chk_dev + 2 * kChkQ + 8, d_keep.p + (m - 1), d_newidx.p + (m - 1),
+                           d_keepnnz.p + (m - 1), d_newptr.p + (m - 1), (const double*)nullptr,
+                           deduped ? (const int32_t*)(d_anynf.p + 1) : (const int32_t*)nullptr, (const int32_t*)nullptr);
+        sync();
+        for (int k = 0; k < 4; ++k) t[k] = (int64_t)ht[k];
+        nd = (int32_t)ht[5];
+    } else {
+        if (deduped) KTN_HIP(hipMemcpyAsync(&nd, d_anynf.p + 1, 4, hipMemcpyDeviceToHost, stream));
+        KTN_HIP(hipMemcpyAsync(&t[0], d_keep.p + (m - 1), 8, hipMemcpyDeviceToHost, stream));
+        KTN_HIP(hipMemcpyAsync(&t[1], d_newidx.p + (m - 1), 8, hipMemcpyDeviceToHost, stream));
+        KTN_HIP(hipMemcpyAsync(&t[2], d_keepnnz.p + (m - 1), 8, hipMemcpyDeviceToHost, stream));
+        KTN_HIP(hipMemcpyAsync(&t[3], d_newptr.p + (m - 1), 8, hipMemcpyDeviceToHost, stream));
+        sync();
+    }
+    stats["deduped_rows"] += (double)nd;
     const int64_t m_new = t[0] + t[1], nnz_new = t[2] + t[3];
     if (m - m_new < (int64_t)(prm.purge_min_frac * (double)m) || m_new == m) return;
     lp_rowptr2.resize((size_t)m_new + 1, stream); lp_col2.resize((size_t)nnz_new + 1, stream);
