@@ -1642,6 +1642,30 @@ __global__ __launch_bounds__(kBlock) void k_scale_stat(int64_t m, const int64_t*
     acc = mode ? group_sum<G>(acc) : group_max<G>(acc);
     if (lane == 0) out[i] = dself[i] * acc;
 }
+// statistic and update in one launch: dnew_i = dself_i / sqrt(dself_i * stat_i) (unchanged where the statistic is 0 or not
+// finite) -- the arithmetic of k_scale_stat followed by k_scale_apply2, without the third launch of every pass.  Rows and
+// columns both read the OLD scalings and write new arrays, which the host swaps in after the pass.
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_scale_stat_upd(int64_t m, const int64_t* __restrict__ ptr,
+                                                           const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                           const double* __restrict__ dself, const double* __restrict__ dother,
+                                                           int mode, double* __restrict__ dnew) {
+    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (i >= m) return;
+    double acc = 0.0;
+    for (int64_t e = ptr[i] + lane; e < ptr[i + 1]; e += G) {
+        const double v = fabs(val[e]) * dother[idx[e]];
+        acc = mode ? acc + v : fmax(acc, v);
+    }
+    acc = mode ? group_sum<G>(acc) : group_max<G>(acc);
+    if (lane == 0) {
+        double d = dself[i];
+        const double st = d * acc;
+        if (st > 0.0 && isfinite(st)) d /= sqrt(st);
+        dnew[i] = d;
+    }
+}
 // the same with the long rows left to k_scale_stat_long (one 1024-thread workgroup per long row)
 template <int G>
 __global__ __launch_bounds__(kBlock) void k_scale_stat_skip(int64_t m, const int64_t* __restrict__ ptr,
