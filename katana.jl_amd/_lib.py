@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkatana_hip.so")
+LIB_PATH = os.environ.get("KTN_LIB") or os.path.join(HERE, "libkatana_hip.so")      # (KTN_LIB: an alternative build, for A/B timing)
 
 KTN_OK = 0
 E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5
