@@ -152,6 +152,11 @@ typedef struct {
     double  polish_factor;  /* 1e-3    0 or >= 1: off                                                                            */
     int32_t polish_max_var; /* 32      only for problems with at most this many LP columns (where the exact LP kernel applies) */
     int32_t polish_max_iter;/* 30      at most this many refinement passes                                                     */
+    /* nonlinear objective (EpigraphNLPEvaluator, src/nlpeval.jl:42-63): every epigraph cut is dense and, close to the optimum, nearly
+       parallel to every other one.  The first-order LP works on the exactly equivalent problem in which the epigraph variable
+       is measured from the NEWEST cut, t = s + grad f(x_k)'x + b_k: the cuts' common part moves into the cost vector and the rows
+       keep only their differences (csrc/kernels.hpp "epigraph reference shift").  The LP that getKatanaCuts exports is unchanged. */
+    int32_t epi_shift;      /* 1       0 = solve the LP in the reference's own form                                              */
 } ktn_params;
 
 /* The device-evaluable statement of the NLP: replaces the

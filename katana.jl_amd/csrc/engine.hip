@@ -246,6 +246,24 @@ struct Engine {
     DBuf<int64_t> c_ptr, c_cnt;
     DBuf<int32_t> c_row;
     DBuf<double> c_val, c_sval, r_sval;
+    // Working form of the LP during a first-order solve with a nonlinear objective: the epigraph cuts relative to the newest one
+    // (kernels.hpp "epigraph reference shift").  The stored LP keeps the reference's form; w_shift says that the CSC mirror,
+    // the scaling and the w* arrays currently hold the shifted problem.
+    bool w_shift = false;
+    int64_t M_lin = 0;                          // LP rows [0, M_lin) are the pass-through linear rows: never epigraph cuts
+    DBuf<double> wval, wlo, whi, wc, epi_ref, epi_scal;      // epi_scal: [0] b_ref, [1] a_ref'x
+    DBuf<unsigned long long> epi_newest;
+    const double* Wval() const { return w_shift ? wval.p : lp_val.p; }
+    const double* Wlo() const { return w_shift ? wlo.p : lp_lo.p; }
+    const double* Whi() const { return w_shift ? whi.p : lp_hi.p; }
+    const double* Wc() const { return w_shift ? wc.p : lp_c.p; }
+    bool want_shift(int mode) const { return prm.epi_shift != 0 && !obj_linear && mode == 0 && !row_sharded() && n_blocks == 0; }
+    void build_working();
+    void ensure_matrix(bool shift);
+    void epi_dot(const double* x) {             // epi_scal[1] = a_ref'x  (a_ref is zero at the epigraph variable)
+        hipLaunchKernelGGL(k_dot_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, n_lp, epi_ref.p, x, partials.p);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, epi_scal.p + 1);
+    }
     DBuf<uint64_t> k_in, k_out;
     DBuf<uint32_t> p_in, p_out;
     DBuf<char> d_sorttmp;
@@ -1186,7 +1204,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     lp_y.resize((size_t)M, stream); lp_y.zero(stream);
     lp_c.upload(cvec, stream); lp_l.upload(lv, stream); lp_u.upload(uv, stream);
     lp_x.resize((size_t)n_lp, stream); lp_x.zero(stream);
-    M_base = M; NNZ_base = NNZ; numcuts_base = numcuts;
+    M_base = M; NNZ_base = NNZ; numcuts_base = numcuts; M_lin = n_lin;
     {
         // room for three sweeps' worth of cuts (each sweep adds at most min(m_nl, cut cap) rows)
         int64_t per_sweep = m_nl;
@@ -1258,11 +1276,44 @@ void Engine::rebuild_csc() {
         // keys are (col << 32 | row) in CSR order, i.e. already ascending in row: a STABLE sort on the column bits alone
         // gives (col, row) order in 3 radix passes instead of 7
         KTN_HIP(sort_pairs_u64_u32(d_sorttmp.p, need, k_in.p, k_out.p, p_in.p, p_out.p, (size_t)NNZ, 32, 32 + bits, stream));
-        LAUNCH_1(k_csc_gather, NNZ, stream, NNZ, k_out.p, p_out.p, lp_val.p, c_row.p, c_val.p);
+        LAUNCH_1(k_csc_gather, NNZ, stream, NNZ, k_out.p, p_out.p, Wval(), c_row.p, c_val.p);
         check_launch();
     }
     lp_dirty = false;
     blocks_built_rows = -1;
+}
+
+// The matrix a solve works on: the stored LP, or its epigraph-shifted working form (kernels.hpp "epigraph reference
+// shift"); rebuilt -- together with the column mirror -- when rows changed or the form toggles.
+void Engine::ensure_matrix(bool shift) {
+    if (shift != w_shift) { lp_dirty = true; ++lp_version; }
+    if (!lp_dirty) return;
+    w_shift = shift;
+    if (shift) build_working();
+    rebuild_csc();
+}
+void Engine::build_working() {
+    const int32_t tcol = (int32_t)n0;
+    const size_t mm = (size_t)std::max<int64_t>(M, 1);
+    wval.resize((size_t)NNZ + 1, stream); wlo.resize(mm, stream); whi.resize(mm, stream);
+    wc.resize((size_t)n_lp, stream); epi_ref.resize((size_t)n_lp, stream); epi_scal.resize(2, stream); epi_newest.resize(1, stream);
+    if (NNZ > 0) KTN_HIP(hipMemcpyAsync(wval.p, lp_val.p, (size_t)NNZ * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    if (M > 0) {
+        KTN_HIP(hipMemcpyAsync(wlo.p, lp_lo.p, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        KTN_HIP(hipMemcpyAsync(whi.p, lp_hi.p, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    }
+    epi_ref.zero(stream); epi_scal.zero(stream); epi_newest.zero(stream);
+    const int64_t rows = M - M_lin;
+    LAUNCH_1(k_epi_newest, rows, stream, M_lin, M, lp_rowptr.p, lp_col.p, tcol, epi_newest.p);
+    if (rows > 0) {
+        hipLaunchKernelGGL(k_epi_setref, dim3(64), dim3(kBlock), 0, stream, epi_newest.p, lp_rowptr.p, lp_col.p, lp_val.p, lp_lo.p, lp_hi.p,
+                           tcol, epi_ref.p, epi_scal.p);
+        hipLaunchKernelGGL(k_epi_shift, dim3((unsigned)(rows * kEpiChunks)), dim3(kBlock), 0, stream, M_lin, M, lp_rowptr.p, lp_col.p,
+                           lp_val.p, lp_lo.p, lp_hi.p, tcol, epi_ref.p, epi_scal.p, wval.p, wlo.p, whi.p);
+    }
+    LAUNCH_1(k_epi_cost, n_lp, stream, n_lp, lp_c.p, tcol, epi_ref.p, wc.p);
+    check_launch();
+    stats["lp_epi_shifts"] += 1.0;
 }
 
 // Cut-pool management after an LP solve (k_purge_mark / k_purge_copy / k_purge_relink).
@@ -1367,6 +1418,7 @@ void Engine::compute_scaling(bool identity) {
     }
     const int gr = pick_group((double)NNZ / (double)std::max<int64_t>(M, 1));
     const int gc = pick_group((double)NNZ / (double)std::max<int64_t>(n_lp, 1));
+    const double cap_c = w_shift ? 1e3 : kInf;          // (kernels.hpp k_scale_apply2)
     if (!identity && (M > 0 || row_sharded())) {
         const int passes = warm ? prm.lp_ruiz_warm : prm.lp_ruiz_iters;
         for (int it = 0; it <= passes; ++it) {
@@ -1378,31 +1430,31 @@ void Engine::compute_scaling(bool identity) {
             if (n_long == 0 && !row_sharded() && M > 0) {
                 // statistic + update in one launch per side, into new arrays that are swapped in (22 launches instead of 33)
                 dr2.resize((size_t)M, stream); dc2.resize((size_t)n_lp, stream);
-                LAUNCH_G(gr, k_scale_stat_upd, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, mode, dr2.p);
-                LAUNCH_G(gc, k_scale_stat_upd, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, dc2.p);
+                LAUNCH_G(gr, k_scale_stat_upd, M, stream, M, lp_rowptr.p, lp_col.p, Wval(), dr.p, dc.p, mode, dr2.p, kInf);
+                LAUNCH_G(gc, k_scale_stat_upd, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, dc2.p, cap_c);
                 dr.swap(dr2); dc.swap(dc2);
                 continue;
             }
             if (n_long > 0) {
-                LAUNCH_G(gr, k_scale_stat_skip, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, mode, statr.p, kLongRow);
+                LAUNCH_G(gr, k_scale_stat_skip, M, stream, M, lp_rowptr.p, lp_col.p, Wval(), dr.p, dc.p, mode, statr.p, kLongRow);
                 hipLaunchKernelGGL(k_scale_stat_long, dim3((unsigned)n_long), dim3(1024), 0, stream, d_longrows.p, lp_rowptr.p, lp_col.p,
-                                   lp_val.p, dr.p, dc.p, mode, statr.p);
+                                   Wval(), dr.p, dc.p, mode, statr.p);
             } else {
-                LAUNCH_G(gr, k_scale_stat, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, mode, statr.p);
+                LAUNCH_G(gr, k_scale_stat, M, stream, M, lp_rowptr.p, lp_col.p, Wval(), dr.p, dc.p, mode, statr.p);
             }
             LAUNCH_G(gc, k_scale_stat, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, statc.p);
             if (row_sharded()) {                       // a column's max / sum runs over the rows of every rank
                 if (M == 0) LAUNCH_1(k_fill, n_lp, stream, n_lp, statc.p, 0.0);
                 allreduce(statc.p, (size_t)n_lp, mode ? 0 : 1);
             }
-            LAUNCH_1(k_scale_apply2, std::max(M, n_lp), stream, M, dr.p, statr.p, n_lp, dc.p, statc.p);
+            LAUNCH_1(k_scale_apply2, std::max(M, n_lp), stream, M, dr.p, statr.p, n_lp, dc.p, statc.p, cap_c);
         }
     }
     scal_rows = identity ? 0 : M;
     scal_cols = n_lp;
     r_sval.resize((size_t)NNZ + 1, stream);
     c_sval.resize((size_t)NNZ + 1, stream);
-    LAUNCH_G(gr, k_scale_vals, M, stream, M, lp_rowptr.p, lp_col.p, lp_val.p, dr.p, dc.p, r_sval.p);
+    LAUNCH_G(gr, k_scale_vals, M, stream, M, lp_rowptr.p, lp_col.p, Wval(), dr.p, dc.p, r_sval.p);
     LAUNCH_G(gc, k_scale_vals, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, c_sval.p);
     check_launch();
 }
@@ -1897,7 +1949,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         tp = now;
     };
     auto tp = t0;
-    if (lp_dirty) rebuild_csc();
+    ensure_matrix(want_shift(mode));
     lap("lp_csc_time_s", tp);
     // (row-sharded: the versions are per rank while the scaling is a collective -- no reuse there)
     static const bool no_reuse = std::getenv("KTN_NO_SETUP_REUSE") != nullptr;
@@ -1913,9 +1965,13 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     loh.resize(mm, stream); hih.resize(mm, stream); yh.resize(mm, stream); y0h.resize(mm, stream);
     yth.resize(mm, stream); pw.resize(mm, stream);
     const double sgn = (sense == KTN_MAX) ? -1.0 : 1.0;
-    LAUNCH_1(k_prep_cols, n, stream, n, lp_c.p, lp_l.p, lp_u.p, dc.p, lp_x.p, (mode == 1 ? box.p : (double*)nullptr), sgn,
+    LAUNCH_1(k_prep_cols, n, stream, n, Wc(), lp_l.p, lp_u.p, dc.p, lp_x.p, (mode == 1 ? box.p : (double*)nullptr), sgn,
              mode, ch.p, lh.p, uh.p, xh.p);
-    LAUNCH_1(k_prep_rows, m, stream, m, lp_lo.p, lp_hi.p, dr.p, lp_y.p, mode, loh.p, hih.p, yh.p);
+    LAUNCH_1(k_prep_rows, m, stream, m, Wlo(), Whi(), dr.p, lp_y.p, mode, loh.p, hih.p, yh.p);
+    if (w_shift) {                                      // the epigraph variable of the start: s = t - a_ref'x - b_ref
+        epi_dot(lp_x.p);
+        hipLaunchKernelGGL(k_epi_var, dim3(1), dim3(1), 0, stream, xh.p, (int32_t)n0, epi_scal.p, (const double*)dc.p, -1, have_omega ? 0 : 1, sgn, epi_newest.p);
+    }
     check_launch();
     const double avg_r = m ? (double)NNZ / (double)m : 1.0, avg_c = n ? (double)NNZ / (double)n : 1.0;
     grp_rows = pick_group(avg_r);
@@ -2020,9 +2076,16 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     if (NNZ > 0) reduce_into(false, NNZ, r_sval.p, 2);
     reduce_into(false, n, ch.p, 3);
     if (m > 0) { reduce_into(true, m, loh.p, 4); reduce_into(true, m, hih.p, 5); }
-    double hs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (w_shift) {                                      // ||c|| of the STORED cost vector: the scale of the (unscaled) dual-residual tolerance
+        hipLaunchKernelGGL(k_dot_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, lp_c.p, lp_c.p, partials.p);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, slots + 6);
+    }
+    double hs[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     KTN_HIP(hipMemcpyAsync(hs, slots, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    double epi_b = 0.0;                                 // b_ref of the working form: the objective constant it carries
+    if (w_shift) KTN_HIP(hipMemcpyAsync(&epi_b, epi_scal.p, sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
+    const double obj_shift = sgn * epi_b;               // internal objective of the stored LP = working objective + obj_shift
     if (have_power) {
         const double nv2 = hs[1];
         smax = (nv2 > 0.0) ? std::sqrt(std::sqrt(nv2)) : 0.0;     // sigma_max^2 ~ ||A'A v||
@@ -2040,12 +2103,16 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     double r_last_check = 0.0;
     stats["lp_setup_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double nc2 = hs[3];
+    const double nc2_tol = w_shift ? hs[6] : nc2;       // (the working cost carries a_ref: not the scale the dual residual is judged on)
     double nb2 = (m > 0) ? hs[4] + hs[5] : 0.0;
     allreduce_host(&nb2, 1, 0);
     const double omega_ref = (nc2 > 0.0 && nb2 > 0.0) ? std::sqrt(nc2 / nb2) : 1.0;
     double om = (have_omega && mode == 0) ? omega : omega_ref;
     const double rho = 1.0;
     const double cinf_scale = 1.0;
+    if (std::getenv("KTN_DEBUG_LP"))
+        std::fprintf(stderr, "[lp setup mode %d] m %lld n %lld nnz %lld smax %.4g fro %.4g nc2 %.4g nc2_tol %.4g nb2 %.4g omega_ref %.4g om0 %.4g shift %d b_ref %.9g n_long %lld tol_p %.3g tol_g %.3g\n",
+                     mode, (long long)m, (long long)n, (long long)NNZ, smax, fro, nc2, nc2_tol, nb2, omega_ref, om, (int)w_shift, epi_b, (long long)n_long, tol_p, tol_g);
 
     // anchors z0 = z; with the packed records of the plain steps (not for the tiled / row-sharded forms, whose steps are
     // split into SpMV + element-wise kernels)
@@ -2122,9 +2189,9 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         }
         if (prm.profile) ev_flush();
         const double dyAdx = q[0], dy2 = q[1], dobj_rows = q[2], dy0sq = q[3], yt2 = q[4], pviol = q[12];
-        const double dx2 = q[kChkQ + 5], pobj = q[kChkQ + 6], dobj_cols = q[kChkQ + 7], dx0sq = q[kChkQ + 8],
+        const double dx2 = q[kChkQ + 5], pobj = q[kChkQ + 6] + obj_shift, dobj_cols = q[kChkQ + 7], dx0sq = q[kChkQ + 8],
                      xt2 = q[kChkQ + 9], dres = q[kChkQ + 13];
-        const double dobj = dobj_rows + dobj_cols;
+        const double dobj = dobj_rows + dobj_cols + obj_shift;
         const double r2 = om / eta * dx2 - 2.0 * dyAdx + dy2 / (eta * om);
         const double r = std::sqrt(std::max(r2, 0.0));
         const double gap = std::fabs(pobj - dobj) / (1.0 + std::fabs(pobj) + std::fabs(dobj));
@@ -2132,8 +2199,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         if (dbg_lp) std::fprintf(stderr, "[lp mode %d] it %7lld k %6lld r %.3e pviol %.3e dres %.3e gap %.3e pobj %.10g dobj %.10g om %.3g eta %.3g\n",
                                  mode, (long long)it, (long long)k, r, pviol, dres, gap, pobj, dobj, om, eta);
         R.pobj = pobj; R.dobj = dobj; R.row_viol = pviol; R.gap = gap;
-        bool done = (pviol <= tol_p) && (gap <= tol_g) && (dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2)));
-        near_conv = (pviol <= 4.0 * tol_p) && (gap <= 4.0 * tol_g) && (dres * cinf_scale <= 4.0 * tol_g * (1.0 + std::sqrt(nc2)));
+        bool done = (pviol <= tol_p) && (gap <= tol_g) && (dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2_tol)));
+        near_conv = (pviol <= 4.0 * tol_p) && (gap <= 4.0 * tol_g) && (dres * cinf_scale <= 4.0 * tol_g * (1.0 + std::sqrt(nc2_tol)));
         // Primal-stagnation exit (lp_stag_factor).  On LPs with degenerate duals the primal part converges within a few
         // hundred iterations while the duality gap crawls for 10 000 more: stop when the rows are
         // feasible to tol_p, the dual residual is converged, the primal objective has not moved by more than 0.1 tol_g
@@ -2150,7 +2217,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
                 const double accept0 = (tol_p > prm.lp_tol_floor * prm.f_tol * (1.0 + 1e-9)) ? 10.0 : 3.0;
                 const bool plateau = pviol <= accept0 * tol_p && std::fabs(pviol - pviol_h[0]) <= 0.02 * pviol &&
                                      std::fabs(pviol - pviol_h[1]) <= 0.02 * pviol && std::fabs(pviol - pviol_h[2]) <= 0.02 * pviol;
-                if (flat && (pviol <= tol_p || plateau) && gap <= stag * tol_g && dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2))) {
+                if (flat && (pviol <= tol_p || plateau) && gap <= stag * tol_g && dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2_tol))) {
                     done = true;
                     stats["lp_stagnation_exits"] += 1.0;
                 }
@@ -2163,7 +2230,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             // its x* only has to be a useful separation point, cuts are valid anywhere) accepts up to 10 tol_p -- the new cuts
             // of the next sweep are what ends such a stall (263 000 iterations at 6.25e-2 against 3e-2 otherwise).
             const double stall_accept = (tol_p > prm.lp_tol_floor * prm.f_tol * (1.0 + 1e-9)) ? 10.0 : 3.0;
-            if (stag > 0.0 && mode == 0 && !done && gap <= tol_g && dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2)) &&
+            if (stag > 0.0 && mode == 0 && !done && gap <= tol_g && dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2_tol)) &&
                 pviol <= stall_accept * tol_p && std::fabs(pviol - pviol_h[0]) <= 0.02 * pviol && std::fabs(pviol - pviol_h[1]) <= 0.02 * pviol &&
                 std::fabs(pviol - pviol_h[2]) <= 0.02 * pviol) {
                 done = true;
@@ -2215,17 +2282,17 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         //  is a no-op)
         const bool have_lists = row_sharded() ? (prm.lp_dual_inherit != 0) : (prm.lp_dual_inherit && lists_ok() && list_count() > 0 && m > M_base);
         if (mode == 0 && k > 0 && have_lists && gap <= tol_g &&
-            dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2)) && pviol > tol_p) {
+            dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2_tol)) && pviol > tol_p) {
             flat_rows = (r_last_check > 0.0 && r > 0.98 * r_last_check) ? flat_rows + 1 : 0;
             if (flat_rows >= 3 && consolidations < 8) {
                 flat_rows = 0;
                 ++consolidations;
                 stats["lp_consolidations"] += 1.0;
                 LAUNCH_1(k_unscale, n, stream, n, xth.p, dc.p, pv.p);
-                SpMat Au{lp_rowptr.p, lp_col.p, lp_val.p};
+                SpMat Au{lp_rowptr.p, lp_col.p, Wval()};
                 LAUNCH_G(grp_rows, k_spmv, m, stream, m, Au, pv.p, pw.p);
                 KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
-                LAUNCH_1(k_consolidate, list_count(), stream, list_count(), list_heads(), d_cutprev.p, pw.p, lp_lo.p, lp_hi.p, dr.p, tol_p, yth.p,
+                LAUNCH_1(k_consolidate, list_count(), stream, list_count(), list_heads(), d_cutprev.p, pw.p, Wlo(), Whi(), dr.p, tol_p, yth.p,
                          d_anynf.p + 1);
                 LAUNCH_1(k_restart_set, std::max(n, m), stream, n, m, xth.p, xh.p, x0h.p, yth.p, yh.p, y0h.p, packed_on ? d_crec.p : (ColRec*)nullptr,
                          packed_on ? d_rrec.p : (RowRec*)nullptr);
@@ -2263,6 +2330,10 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     if (mode == 0) {
         LAUNCH_1(k_unscale, n, stream, n, xth.p, dc.p, lp_x.p);
         LAUNCH_1(k_unscale, m, stream, m, yth.p, dr.p, lp_y.p);
+        if (w_shift) {                                  // back to the epigraph variable of the stored LP: t = s + a_ref'x + b_ref
+            epi_dot(lp_x.p);
+            hipLaunchKernelGGL(k_epi_var, dim3(1), dim3(1), 0, stream, lp_x.p, (int32_t)n0, epi_scal.p, (const double*)nullptr, 1, 0, sgn, epi_newest.p);
+        }
         omega = om;
         have_omega = true;
         objval = sgn * R.pobj + c0;
@@ -2280,7 +2351,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
 
 void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double omega_, int64_t iters, double* x_out,
                       double* y_out) {
-    if (lp_dirty) rebuild_csc();
+    ensure_matrix(false);
     compute_scaling(true);
     scaled_version = 0;                                  // (lp_solve_core must not take this identity scaling for its own)
     const int64_t n = n_lp, m = M;
@@ -2576,6 +2647,7 @@ void ktn_default_params(ktn_params* p) {
     p->lp_stag_factor = 100.0;
     p->lp_ruiz_warm = 0; p->lp_tiled_nnz = 4000000; p->lp_near_check = 7; p->dedupe_eps = 1e-6;
     p->polish_factor = 1e-3; p->polish_max_var = 32; p->polish_max_iter = 30;
+    p->epi_shift = 1;
 }
 
 int ktn_create(const ktn_params* p, ktn_handle* out) {

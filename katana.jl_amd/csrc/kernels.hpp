@@ -1649,7 +1649,7 @@ template <int G>
 __global__ __launch_bounds__(kBlock) void k_scale_stat_upd(int64_t m, const int64_t* __restrict__ ptr,
                                                            const int32_t* __restrict__ idx, const double* __restrict__ val,
                                                            const double* __restrict__ dself, const double* __restrict__ dother,
-                                                           int mode, double* __restrict__ dnew) {
+                                                           int mode, double* __restrict__ dnew, double cap) {
     const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     if (i >= m) return;
@@ -1663,7 +1663,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_stat_upd(int64_t m, const int6
         double d = dself[i];
         const double st = d * acc;
         if (st > 0.0 && isfinite(st)) d /= sqrt(st);
-        dnew[i] = d;
+        dnew[i] = fmin(d, cap);         // (cap: see k_scale_apply2)
     }
 }
 // the same with the long rows left to k_scale_stat_long (one 1024-thread workgroup per long row)
@@ -1711,12 +1711,15 @@ __global__ __launch_bounds__(kBlock) void k_scale_apply(int64_t m, double* __res
     const double s = stat[i];
     if (s > 0.0 && isfinite(s)) d[i] /= sqrt(s);
 }
-// rows and columns in one launch
+// rows and columns in one launch.  cap_c bounds the column factors: in the epigraph-shifted working form a column that
+// occurs only in the dense cuts holds nothing but DIFFERENCES of nearly equal derivatives (1e-7 ... rounding noise); the
+// equilibration would blow such a column up by that factor and its cost with it (||c^|| 1e17 seen: primal weight and
+// tolerances meaningless).  A smaller factor than Pock-Chambolle's keeps ||A^||_2 <= 1.  (inf for every other solve.)
 __global__ __launch_bounds__(kBlock) void k_scale_apply2(int64_t m, double* __restrict__ dr, const double* __restrict__ sr, int64_t n,
-                                                        double* __restrict__ dc, const double* __restrict__ sc) {
+                                                        double* __restrict__ dc, const double* __restrict__ sc, double cap_c) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < m) { const double s = sr[i]; if (s > 0.0 && isfinite(s)) dr[i] /= sqrt(s); }
-    if (i < n) { const double s = sc[i]; if (s > 0.0 && isfinite(s)) dc[i] /= sqrt(s); }
+    if (i < n) { const double s = sc[i]; if (s > 0.0 && isfinite(s)) dc[i] = fmin(dc[i] / sqrt(s), cap_c); }
 }
 // out[newidx[r]] = in[r] for the kept rows (purge)
 __global__ __launch_bounds__(kBlock) void k_compact_vec(int64_t m, const int64_t* __restrict__ keep, const int64_t* __restrict__ newidx,
@@ -1846,6 +1849,21 @@ __global__ __launch_bounds__(kBlock) void k_dot_partial(int64_t n, const double*
         partials[blockIdx.x] = v;
     }
 }
+// partials[b] = sum of (a_i d_i)^2: the squared norm of a vector in scaled coordinates without materialising it
+__global__ __launch_bounds__(kBlock) void k_scaled_sq_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ d,
+                                                              double* __restrict__ partials) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) { const double v = a[i] * d[i]; acc += v * v; }
+    __shared__ double sh[kBlock / 64];
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = 0.0;
+        for (int k = 0; k < kBlock / 64; ++k) v += sh[k];
+        partials[blockIdx.x] = v;
+    }
+}
 __global__ __launch_bounds__(kRedBlocks) void k_sum_final(const double* __restrict__ partials, int nblocks,
                                                           double* __restrict__ out) {
     __shared__ double sh[kRedBlocks / 64];
@@ -1918,6 +1936,97 @@ __global__ __launch_bounds__(kBlock) void k_aux_box(int64_t m, const int64_t* __
         if (col[e] == aux) av += a;
     }
     if (av > 0.0) atomic_max_nonneg(out, (tot - av) / av);
+}
+
+// ---------------------------------------------------------- epigraph reference shift ----
+// With a nonlinear objective every epigraph cut  grad f(x_k)'x - t {<=,>=} -b_k  (src/nlpeval.jl:49-63, src/model.jl:137-164)
+// is dense, and close to the optimum the cuts are nearly parallel: their common part grad f(x*) dominates every row.  A
+// first-order LP method then idles (multiplier mass moves between two such rows at a rate proportional to the violation;
+// the free variable t couples to them only through a 1/sqrt(n) share of the row norm).  The LP solve therefore works on
+// the column-transformed problem  t = s + a_ref'x + b_ref  with (a_ref, b_ref) the NEWEST epigraph cut:
+//     rows   (a_k - a_ref)'x - s {<=,>=} -(b_k - b_ref)        cost  c_x + c_t a_ref  (+ constant c_t b_ref)
+// an exact change of variables -- same duals, same x, t recovered afterwards -- in which the common part sits in the cost
+// vector and the rows hold only the differences.  The stored LP (lp_val, lp_lo, lp_hi, lp_c: what getKatanaCuts exports,
+// what purging and the exact small-LP kernel read) stays in the reference's form; the solve reads the working copies.
+// An epigraph cut is recognised by its last entry: the epigraph variable has the largest column index (engine.hip, loadproblem).
+__global__ __launch_bounds__(kBlock) void k_epi_newest(int64_t first, int64_t m, const int64_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col, int32_t tcol,
+                                                       unsigned long long* __restrict__ newest_plus1) {
+    const int64_t r = first + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= m) return;
+    const int64_t end = rowptr[r + 1];
+    if (end > rowptr[r] && col[end - 1] == tcol) atomicMax(newest_plus1, (unsigned long long)(r + 1));
+}
+// a_ref (dense, zero-initialised by the caller) and b_ref from the newest epigraph cut; scal[0] = b_ref, scal[1] = a_ref'x (later)
+__global__ __launch_bounds__(kBlock) void k_epi_setref(const unsigned long long* __restrict__ newest_plus1,
+                                                       const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       const double* __restrict__ val, const double* __restrict__ lo,
+                                                       const double* __restrict__ hi, int32_t tcol, double* __restrict__ aref,
+                                                       double* __restrict__ scal) {
+    const int64_t r = (int64_t)newest_plus1[0] - 1;
+    if (r < 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = 0.0;
+        return;
+    }
+    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+    for (int64_t e = beg + (int64_t)blockIdx.x * kBlock + threadIdx.x; e < end; e += (int64_t)gridDim.x * kBlock) {
+        const int32_t c = col[e];
+        if (c != tcol) aref[c] = val[e];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double h = hi[r], l = lo[r];
+        const double b = isfinite(h) ? -h : (isfinite(l) ? -l : 0.0);     // a cut has one finite side (src/model.jl:74-75)
+        scal[0] = b;
+    }
+}
+// working copies of the epigraph cuts: kEpiChunks workgroups per LP row from `first` on (all others return at once)
+constexpr int kEpiChunks = 16;
+__global__ __launch_bounds__(kBlock) void k_epi_shift(int64_t first, int64_t m, const int64_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                      const double* __restrict__ lo, const double* __restrict__ hi, int32_t tcol,
+                                                      const double* __restrict__ aref, const double* __restrict__ scal,
+                                                      double* __restrict__ wval, double* __restrict__ wlo, double* __restrict__ whi) {
+    const int64_t r = first + (int64_t)blockIdx.x / kEpiChunks;
+    const int chunk = (int)(blockIdx.x % kEpiChunks);
+    if (r >= m) return;
+    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+    if (end <= beg || col[end - 1] != tcol) return;
+    for (int64_t e = beg + (int64_t)chunk * kBlock + threadIdx.x; e < end; e += (int64_t)kEpiChunks * kBlock) {
+        const int32_t c = col[e];
+        if (c != tcol) {
+            const double a = val[e], b = aref[c], d = a - b;
+            wval[e] = (fabs(d) <= 1e-14 * (fabs(a) + fabs(b))) ? 0.0 : d;      // rounding noise of two equal derivatives
+        }
+    }
+    if (chunk == 0 && threadIdx.x == 0) { wlo[r] = lo[r] + scal[0]; whi[r] = hi[r] + scal[0]; }
+}
+// working cost: c_x + c_t a_ref  (a_ref[tcol] == 0)
+__global__ __launch_bounds__(kBlock) void k_epi_cost(int64_t n, const double* __restrict__ c, int32_t tcol,
+                                                     const double* __restrict__ aref, double* __restrict__ wc) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j < n) wc[j] = c[j] + c[tcol] * aref[j];
+}
+// t <-> s around a solve (scal[1] = a_ref'x of the unscaled x):
+//   dir = -1: xh[tcol] = s / dc[tcol] with s = t - a_ref'x - b_ref, put on the feasible side of the reference cut -- whose
+//             working row is simply s >= 0 (Min) / s <= 0 (Max) whatever x is: a NEW reference cut is violated at the
+//             previous LP point by f(x) - t (1e6 early on), and started from there PDHG over-shoots by as much and then
+//             drifts back at the pace of the primal step.  first = 1 (no earlier solve): s = 0, i.e. t starts AT the
+//             reference cut's value -- from t = 0 it would have to travel |a_ref'x + b_ref| the same way.
+//   dir = +1: x[tcol]  += a_ref'x + b_ref                (x unscaled, after the solve)
+__global__ void k_epi_var(double* __restrict__ x, int32_t tcol, const double* __restrict__ scal, const double* __restrict__ d, int dir,
+                          int first, double sgn, const unsigned long long* __restrict__ newest_plus1) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const double off = scal[1] + scal[0];
+    if (dir < 0) {
+        double s = x[tcol] - off / d[tcol];
+        if (newest_plus1[0] > 0) {                       // (without any epigraph cut there is no reference row: s = t)
+            if (first) s = 0.0;
+            else s = (sgn > 0.0) ? fmax(s, 0.0) : fmin(s, 0.0);
+        }
+        x[tcol] = s;
+    } else {
+        x[tcol] += off;
+    }
 }
 
 }  // namespace ktn

@@ -40,6 +40,8 @@ CONFIGS = {
     # through the (dense) epigraph row f(x) - t <= 0 (src/nlpeval.jl:42-63; SURVEY.md section 8d "cfg2 QP variant")
     "cfg2_qp": dict(n=10_000, m_nl=1_000, k=64, family="quad", objective="quad"),
     "cfg3": dict(n=100_000, m_nl=10_000, k=32, family="explog"),
+    # the north star's shape with the nonlinear-objective path switched on (src/nlpeval.jl:42-63): every epigraph cut has 1e5 entries
+    "cfg3_qp": dict(n=100_000, m_nl=10_000, k=32, family="explog", objective="quad"),
     "cfg3_hbm": dict(n=100_000, m_nl=10_000, k=2048, family="explog"),
     "cfg4": dict(n=100_000, m_nl=1_000_000, k=32, family="explog"),
     "cfg5_one": dict(n=1_000, m_nl=100, k=16, family="explog"),
