@@ -45,6 +45,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_ROUND = "r03"      # profiles/<round>_kernel_stats.csv, <round>_traffic.json: the rocprofv3 summaries of THIS command
+
+
+def rocprof_avg_ns(csv_name, kernel_prefix):
+    """Call-weighted mean duration (ns) of the kernels whose name starts with `kernel_prefix` in a committed
+    rocprofv3 --kernel-trace --stats summary (profiles/<csv_name>); None when the file or the kernel is absent."""
+    import csv
+    path = os.path.join(ROOT, "profiles", csv_name)
+    if not os.path.exists(path):
+        return None
+    calls = total = 0.0
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            name = row.get("Name", "")
+            if name.startswith("void ktn::" + kernel_prefix) or name.startswith("ktn::" + kernel_prefix) or name.startswith(kernel_prefix):
+                calls += float(row["Calls"])
+                total += float(row["TotalDurationNs"])
+    return total / calls if calls else None
+
+
+def with_rocprof(r, csv_name, kernel_prefix):
+    """`frac` / `achieved` of a roofline record from the rocprofv3 duration of the same kernel in profiles/ (profiled passes run
+    a little slower than the in-process hipEvents: the conservative figure is the headline, the live one stays beside it)."""
+    r["achieved_inprocess"], r["frac_inprocess"] = r["achieved"], r["frac"]
+    ns = rocprof_avg_ns(csv_name, kernel_prefix)
+    if ns:
+        r["avg_launch_us_rocprof"] = ns / 1e3
+        r["achieved"] = r["algorithmic_bytes_per_launch"] / (ns * 1e-9) / 1e9
+        r["frac"] = r["achieved"] / HBM_PEAK_GBS
+        r["frac_source"] = "algorithmic bytes of this run / mean duration of %s in profiles/%s (rocprofv3 --kernel-trace --stats of this command)" % (kernel_prefix, csv_name)
+    else:
+        r["frac_source"] = "in-process hipEvents (no profiles/%s)" % csv_name
+    return r
 
 
 def parse():
@@ -55,6 +88,7 @@ def parse():
     ap.add_argument("--workload", default=None, help="default: cfg3 on one GPU, cfg4 on several")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline-mt", action="store_true", help="skip the second CPU line (HiGHS default threading)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sweep-roofline", action="store_true")
     ap.add_argument("--no-spmv-roofline", action="store_true")
@@ -102,6 +136,18 @@ def cpu_baseline(args):
     t0 = time.perf_counter()
     status = om.optimize()
     wall = time.perf_counter() - t0
+    # "also report HiGHS with its default threading as a second, more favourable CPU line"
+    mt = None
+    if not args.no_cpu_baseline_mt:
+        om2 = OracleModel(KatanaModelParams(), fast=True, lp_threads=0)
+        om2.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense, d)
+        t0 = time.perf_counter()
+        st2 = om2.optimize()
+        w2 = time.perf_counter() - t0
+        mt = {"value": om2.numiters() / w2, "unit": "ECP iterations/s", "cores": os.cpu_count(), "kind": "port",
+              "sample": "the same solve with HiGHS left to its default threading and simplex strategy (threads = 0: automatic, "
+                        "%d host cores visible)" % os.cpu_count(),
+              "status": st2, "ecp_iters": om2.numiters(), "wall_s": w2, "obj": om2.getobjval()}
     # the same sample on the GPU, for a like-for-like ratio
     m = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0))
     m.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense,
@@ -119,7 +165,7 @@ def cpu_baseline(args):
                                               else "family at scale %g" % args.cpu_baseline_scale, inst.n, inst.m_lin, inst.m_nl,
                                               cfg["k"], args.seed),
         "status": status, "ecp_iters": om.numiters(), "wall_s": wall, "obj": om.getobjval(), "planted_obj": inst.opt_obj,
-        "host_cores_available": os.cpu_count(),
+        "host_cores_available": os.cpu_count(), "default_threading": mt,
         "gpu_on_same_sample": {"value": m.numiters() / gwall, "wall_s": gwall, "ecp_iters": m.numiters(),
                                "status": gstatus, "obj": m.getobjval()},
     }
@@ -284,15 +330,17 @@ def main():
         oth = "ky" if dom == "kx" else "kx"
         roofline = rf(dom, names[dom])
         roofline["total_time_s_in_run"] = d[dom + "_time_s"]
+        if args.workload == "cfg3":
+            with_rocprof(roofline, PROFILE_ROUND + "_kernel_stats.csv", "k_pdhg_x_packed" if dom == "kx" else "k_pdhg_y_packed")
         # HBM traffic from the PMC counters cannot be collected in-process; the per-launch figure of the committed
         # rocprofv3 --pmc passes over this same command is reported (profiles/r02_traffic.json, regenerated every round)
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_traffic.json")
         if os.path.exists(tpath) and args.workload == "cfg3":
             t = json.load(open(tpath))
             key = "k_pdhg_x" if dom == "kx" else "k_pdhg_y"
             if key in t:
                 roofline["traffic"] = t[key]["bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE, separate passes; see its _note)"
+                roofline["traffic_source"] = "profiles/%s_traffic.json (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE, separate passes; see its _note)" % PROFILE_ROUND
         roofline["other_kernels"] = {
             ("k_pdhg_x" if oth == "kx" else "k_pdhg_y"): rf(oth, names[oth]),
             "k_sep_eval": rf("sweep_eval", "k_sep_eval (separator sweep: g, cut constant, violation)"),
@@ -319,12 +367,20 @@ def main():
                           "kernel": "k_sep_eval_blk + k_sep_combine (column-blocked separator sweep)",
                           "workload": "cfg3_hbm: n=%d, m_nl=%d exp/log rows, k=%d" % (hb.n, hb.m_nl, hb.meta["k"]),
                           "launches": int(dn), "avg_launch_us": 1e6 * dt / dn, "algorithmic_bytes_per_launch": db / dn, "traffic": None}
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_traffic.json")
         if os.path.exists(tpath):
             t = json.load(open(tpath)).get("k_sep_eval_blk")
             if t:
                 sweep_roofline["traffic"] = t["bytes_per_launch"]
-                sweep_roofline["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction for 16-B/lane streams)"
+                sweep_roofline["traffic_source"] = "profiles/%s_traffic.json (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction for 16-B/lane streams)" % PROFILE_ROUND
+        # the sweep is two kernels per pass (blocked evaluation + combination): the rocprofv3 figure is the sum of their means
+        ns_blk, ns_cmb = rocprof_avg_ns(PROFILE_ROUND + "_sweep_hbm_kernel_stats.csv", "k_sep_eval_blk"), rocprof_avg_ns(PROFILE_ROUND + "_sweep_hbm_kernel_stats.csv", "k_sep_combine")
+        sweep_roofline["achieved_inprocess"], sweep_roofline["frac_inprocess"] = sweep_roofline["achieved"], sweep_roofline["frac"]
+        if ns_blk and ns_cmb:
+            sweep_roofline["avg_launch_us_rocprof"] = (ns_blk + ns_cmb) / 1e3
+            sweep_roofline["achieved"] = sweep_roofline["algorithmic_bytes_per_launch"] / ((ns_blk + ns_cmb) * 1e-9) / 1e9
+            sweep_roofline["frac"] = sweep_roofline["achieved"] / HBM_PEAK_GBS
+            sweep_roofline["frac_source"] = "profiles/%s_sweep_hbm_kernel_stats.csv (k_sep_eval_blk + k_sep_combine)" % PROFILE_ROUND
         del sm, sep, hb
 
     # The box's practical streaming ceilings next to the 8 TB/s spec figure `peak` ("quote the copy-kernel
@@ -350,6 +406,7 @@ def main():
 
     # The LP SpMV steps in the HBM regime (tools/spmv_bench.py): cfg4's LP after one un-capped sweep
     spmv_roofline = None
+    sweep_short = None
     if world == 1 and not args.no_roofline and not args.no_spmv_roofline and args.workload == "cfg3":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import spmv_bench
@@ -371,12 +428,33 @@ def main():
                                               "achieved": by / tt / 1e9, "frac": by / tt / 1e9 / HBM_PEAK_GBS}
         worst = min(spmv_roofline["kernels"].values(), key=lambda r: r["frac"])
         spmv_roofline["achieved"], spmv_roofline["frac"] = worst["achieved"], worst["frac"]
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_traffic.json")
         if os.path.exists(tpath):
             t = json.load(open(tpath)).get("k_spmv_tiled")
             if t:
                 spmv_roofline["traffic"] = t["bytes_per_launch"]
-                spmv_roofline["traffic_source"] = "profiles/r02_traffic.json (k_spmv_tiled alone; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                spmv_roofline["traffic_source"] = "profiles/%s_traffic.json (k_spmv_tiled alone; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % PROFILE_ROUND
+        # The separator sweep on the SAME instance: 1e6 SHORT rows (k = 32), the kernel that shards over the GPUs under the
+        # north star's NL-row split (DESIGN.md section 4 "the sweep on 1e6 short rows").  Near the optimum: few violated rows.
+        if not args.no_sweep_roofline:
+            sep2 = ktn.KatanaHipSeparator(sm); sep2.initialize()
+            sm.reset()
+            xs2 = np.clip(sinst.xhat + 0.05, sinst.l_var, sinst.u_var)
+            sep2.precompute(xs2)
+            for _ in range(2):
+                sep2.sweep(1e-6); sm.reset(); sep2.precompute(xs2)
+            skeys = ("sweep_eval_time_s", "sweep_eval_launches", "sweep_eval_bytes")
+            b1 = {k: sm.stat(k) for k in skeys}
+            for _ in range(8):
+                nv2, _mv = sep2.sweep(1e-6); sm.reset(); sep2.precompute(xs2)
+            dt, dn, db = (sm.stat(k) - b1[k] for k in skeys)
+            ach = db / dt / 1e9
+            sweep_short = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "k_sep_sweep (row kernel, several short rows per lane group)",
+                           "workload": "cfg4-shaped: n=%d, m_nl=%d exp/log rows, k=%d" % (sinst.n, sinst.m_nl, sinst.meta["k"]),
+                           "launches": int(dn), "avg_launch_us": 1e6 * dt / dn, "algorithmic_bytes_per_launch": db / dn,
+                           "violated_rows_at_the_point": int(nv2)}
+            with_rocprof(sweep_short, PROFILE_ROUND + "_sweep_short_kernel_stats.csv", "k_sep_sweep")
         del sm, sinst
 
     cpu = None
@@ -431,7 +509,8 @@ def main():
             "wall_to_ftol_s": wall_to_ftol, "ecp_iters_to_ftol": iters_to_ftol, "status": status, "objective": obj,
             "planted_objective": inst.opt_obj, "objective_relerr": abs(obj - inst.opt_obj) / max(1.0, abs(inst.opt_obj)),
             "pdhg_iters_per_step": pdhg_timed / args.steps, "solves_in_timed_region": len(solves),
-            "roofline": roofline, "sweep_roofline": sweep_roofline, "spmv_roofline": spmv_roofline, "stream_ceiling": stream_ceiling,
+            "roofline": roofline, "sweep_roofline": sweep_roofline, "sweep_roofline_short_rows": sweep_short,
+            "spmv_roofline": spmv_roofline, "stream_ceiling": stream_ceiling,
             "cpu_baseline": cpu,
             "multi_gpu": multi,
         }

@@ -74,21 +74,25 @@ class FusedBatch:
         self._solved = False
         return self
 
-    def solve(self):
+    def solve(self, cut_capacity=0):
+        """cut_capacity: cuts per NL row an instance's arena has room for in the device-side loop (0: the engine's default, 12);
+        an instance that outgrows it sends the batch to the host-driven loop (stat ecp_blocks_fallbacks)"""
         import numpy as np
         from .instances import atom_value_deriv
         m, big, offs = self.m, self.big, self.offs
         if self._solved:
             m.reset()
         self._solved = True
-        status = m.optimize_blocks() if self.device_loop else m.optimize()
+        status = m.optimize_blocks(cut_capacity) if self.device_loop else m.optimize()
         x = m.getsolution()
         # per-instance objectives: all atoms of the fused objective at once, then sums by instance
         kind, p0, p1, col = self._obj
         val, _ = atom_value_deriv(kind, p0, p1, x[col])
         optr = big.meta["obj_ptr"]
-        seg = np.add.reduceat(val, optr[:-1]) if len(val) else np.zeros(len(self.instances))
-        seg = np.where(np.diff(optr) > 0, seg, 0.0)
+        seg = np.zeros(len(self.instances))
+        nz = np.flatnonzero(np.diff(optr) > 0)                    # (instances with an empty objective are not reduceat starts)
+        if len(nz):
+            seg[nz] = np.add.reduceat(val, optr[:-1][nz])
         common = dict(status=status, iters=m.numiters(), numcuts=None, pdhg_iters=m.stat("pdhg_iters"),
                       blk_lp_launches=m.stat("blk_lp_launches"), blk_lp_fallbacks=m.stat("blk_lp_fallbacks"),
                       blk_pdhg_iters_sum=m.stat("blk_pdhg_iters_sum"), ecp_blocks_launches=m.stat("ecp_blocks_launches"),

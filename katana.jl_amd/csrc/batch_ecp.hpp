@@ -543,17 +543,26 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
         int nnzV = 0;
         if (V > 0) {
             // entry offsets: thread 0 walks the violated rows in order
+            // (capacity is tested BEFORE anything is stored: the row pointers of an arena have cap_rows + 1 slots and the
+            //  next instance's arena follows -- a dry pass for the entry count, the stores only when rows and entries fit)
             if (tid == 0) {
-                int nz = NNZ;
+                int64_t nz = NNZ;
                 for (int i = 0; i < m_nl; ++i) if (icnt[i] & 1) {
                     const int32_t gr = B.nl_rows[nl0 + i];
-                    const int len = (int)(B.P.rowptr[gr + 1] - B.P.rowptr[gr]);
-                    rptr[M + (icnt[i] >> 1)] = nz;
-                    nz += len;
+                    nz += B.P.rowptr[gr + 1] - B.P.rowptr[gr];
                 }
-                rptr[M + V] = nz;
+                const bool fits = (M + V <= A.cap_rows) && (nz <= A.cap_nnz);
+                if (fits) {
+                    int at = NNZ;
+                    for (int i = 0; i < m_nl; ++i) if (icnt[i] & 1) {
+                        const int32_t gr = B.nl_rows[nl0 + i];
+                        rptr[M + (icnt[i] >> 1)] = at;
+                        at += (int)(B.P.rowptr[gr + 1] - B.P.rowptr[gr]);
+                    }
+                    rptr[M + V] = at;
+                }
                 ctl[6] = (double)(nz - NNZ);
-                ctl[7] = (M + V > A.cap_rows || nz > A.cap_nnz) ? 1.0 : 0.0;
+                ctl[7] = fits ? 0.0 : 1.0;
             }
             __syncthreads();
             nnzV = (int)ctl[6];

@@ -175,6 +175,7 @@ struct Engine {
     std::vector<double> h_lb, h_ub;      // per extended row
     std::vector<int32_t> h_nlrows;
     int64_t m_nl = 0, n_tape_nl = 0;
+    int64_t m_nl_global = 0;       // NL rows over all ranks of a row-sharded LP (== m_nl otherwise): decisions that steer collectives use it
     int grp_sweep = 32;
 
     // ---- device NLP ----
@@ -311,6 +312,7 @@ struct Engine {
     bool build_tiled(TiledBuf& T, int64_t n_out, int64_t n_in, const int64_t* ptr, const int32_t* idx, const double* val, int64_t skip_longer);
     // throughput mode (batch_lp.hpp): the loaded problem is block-diagonal, one workgroup per block runs its LP
     int64_t n_blocks = 0, blocks_built_rows = -1;
+    size_t lds_set_lp = 0, lds_set_ecp = 0;      // dynamic-LDS sizes already granted to the two per-instance kernels on this handle's device
     std::vector<int64_t> h_blkcol;
     DBuf<int64_t> d_blkcol;
     DBuf<int32_t> d_blkrowptr, d_blkrows, d_rowloc, d_crowl;
@@ -344,6 +346,7 @@ struct Engine {
     DBuf<double> d_xbest;
     // print_header / print_stats bookkeeping  src/model.jl:209-217,252-254,284-303
     int64_t log_cuts_lastprnt = 0, log_max_viol = 0, purged_total = 0;
+    bool logging() const { return prm.log_level > 0 && dist.rank == 0; }      // (row-sharded: one table, from rank 0)
     void print_header() const {
         std::printf("%-10s %-15s %-15s %-20s %-20s %-15s\n", "Iteration", "Total cuts", "Cuts added", "Max constr. viol.",
                     "Avg constr. viol.", "Current cuts");
@@ -1223,6 +1226,17 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     reset();
     lapl("reset");
     if (keep_status == KTN_STATUS_ERROR) status = KTN_STATUS_ERROR;
+    // row-sharded: what steers the sequence of collectives must be the same on every rank -- the number of NL rows (a rank
+    // whose shard has none would otherwise take the pure-LP tolerance and leave the others' restart pattern) and the
+    // load-time error (the vertex cut of the epigraph row is built on rank 0 only)
+    m_nl_global = m_nl;
+    if (row_sharded()) {
+        double cnt = (double)m_nl, bad = (status == KTN_STATUS_ERROR) ? 1.0 : 0.0;
+        allreduce_host(&cnt, 1, 0);
+        allreduce_host(&bad, 1, 1);
+        m_nl_global = (int64_t)(cnt + 0.5);
+        if (bad > 0.0) status = KTN_STATUS_ERROR;
+    }
 }
 
 void Engine::reset() {
@@ -1536,10 +1550,9 @@ bool Engine::lp_solve_blocks(double tol_p, double tol_g, double eta, LpResult* R
     const size_t lds = (size_t)(3 * blk_nmax + 3 * blk_mmax + (kBlkThreads / 64) * kBlkQ + kBlkQ + 8) * sizeof(double) +
                        (size_t)(blk_mmax + 2) * sizeof(int32_t);
     if (lds > 150 * 1024) return false;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
+    if (lds > lds_set_lp) {        // (per handle: handles live on different devices and host threads)
         KTN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pdhg_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
+        lds_set_lp = lds;
     }
     d_blkres.resize((size_t)nb * 8, stream);
     BlkLp P;
@@ -1657,10 +1670,9 @@ bool Engine::optimize_blocks_device(int cap_mul) {
     B.check_every = std::min(B.check_every, 24);
     B.near_chunk = prm.lp_near_check; B.ruiz_iters = prm.lp_ruiz_iters; B.nmax = blk_nmax; B.mmax = mmax;
     B.power_passes = std::getenv("KTN_ECP_POWER") ? std::atoi(std::getenv("KTN_ECP_POWER")) : 20;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
+    if (lds > lds_set_ecp) {
         KTN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ecp_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
+        lds_set_ecp = lds;
     }
     // the loaded state: M == M_base rows (the linear rows), as after reset()
     hipLaunchKernelGGL(k_ecp_blocks, dim3((unsigned)nb), dim3(kEcpThreads), lds, stream, B);
@@ -1719,6 +1731,7 @@ void Engine::find_long_rows() {
 // hipGraph of the chunk bought nothing measurable while its capture + instantiation cost every LP solve).
 void Engine::launch_y(const SpMat& A, double sigma, double w, double rho, hipEvent_t e0, hipEvent_t e1) {
     const int64_t m = M;
+    if (m == 0) return;                                 // (first LP of a model with NL rows only: no dual step, no zero-size grid)
     const int64_t thr = n_long > 0 ? kLongRow : (int64_t)1 << 62;
     if (tiled_on && m > 0) {
         launch_tiled(tA, m, n_lp, xbar.p, e0);
@@ -2481,7 +2494,7 @@ void Engine::begin() {
             return;
         }
     }
-    if (prm.log_level > 0) { print_header(); std::fflush(stdout); }                           // model.jl:249-251
+    if (logging()) { print_header(); std::fflush(stdout); }                                   // model.jl:249-251
 }
 
 void Engine::step(int32_t* done) {
@@ -2493,7 +2506,7 @@ void Engine::step(int32_t* done) {
     iter += 1;
     const double floor_p = prm.lp_tol_floor * prm.f_tol;
     double tol_p = std::min(std::max(prm.lp_tol_scale * last_maxviol, floor_p), prm.lp_tol_cap);
-    if (m_nl == 0) tol_p = floor_p;      // pure LP: one exact solve, like the reference
+    if (m_nl_global == 0) tol_p = floor_p;      // pure LP: one exact solve, like the reference (row-sharded: NL rows of ALL ranks)
     double tol_g = std::min(std::max(tol_p, prm.lp_gap_floor), prm.lp_gap_cap);
     LpResult R = lp_solve(tol_p, tol_g, 0);
     lp_status = R.status;
@@ -2516,7 +2529,7 @@ void Engine::step(int32_t* done) {
     obj_prev = obj;
     log_max_viol = std::max(log_max_viol, nviol);                        // model.jl:284-285
     log_cuts_lastprnt += last_sweep_cuts;
-    if (prm.log_level > 0) {                                             // model.jl:291-303
+    if (logging()) {                                                     // model.jl:291-303
         const int64_t r = iter % prm.log_level;
         if (r == 0) {
             if (iter % ((int64_t)prm.log_level * 50) == 0) print_header();

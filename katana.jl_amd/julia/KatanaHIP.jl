@@ -8,11 +8,19 @@
 # is that its opcode table, struct mirrors and symbol names agree with include/katana_hip.h and with the
 # Python binding (katana.jl_amd/_lib.py, expr.py), which is exercised on the GPU.
 #
-#     include("KatanaHIP.jl")                       # inside module Katana, after solver.jl
-#     MathProgBase.NonlinearModel(s::KatanaSolver) = KatanaHIP.KatanaHipModel(s)     # src/model.jl:63-65
+#     include("KatanaHIP.jl")                       # inside module Katana, after solver.jl (src/Katana.jl:21)
+#
+# With that one line the methods at the end of this file replace the two model factories of the reference
+# (src/model.jl:63-65, src/solver.jl:46) and `KatanaHipSeparator()` becomes available as a `separator=` keyword of
+# KatanaSolver (src/solver.jl:34-43) for users who keep the reference's own loop and LP solver.
 module KatanaHIP
 
 using MathProgBase
+using JuMP
+import ..KatanaSolver, ..AbstractKatanaSeparator, ..EpigraphNLPEvaluator          # src/solver.jl:6, src/separators.jl:8, src/nlpeval.jl:6
+import ..initialize!, ..precompute!, ..gencut, ..isconstrsat                      # the separator API, src/separators.jl:23-53
+
+export KatanaHipSeparator
 
 const LIB = get(ENV, "KATANA_HIP_LIB", joinpath(dirname(@__FILE__), "..", "libkatana_hip.so"))
 
@@ -173,11 +181,102 @@ function build_ktn_nlp_desc(d::MathProgBase.AbstractNLPEvaluator, num_var::Int, 
     return desc, arrs
 end
 
+# ---- evaluators without :ExprGraph: the host-callback description (KTN_ROW_HOST) ---------------------------
+# An evaluator that cannot hand over expressions (MathProgBase.features_available(d) lacks :ExprGraph -- the reference's own
+# EpigraphNLPEvaluator is one, src/nlpeval.jl:23) is consumed the way the reference consumes it: eval_g + eval_jac_g
+# (src/separators.jl:112-113) and eval_f + eval_grad_f (src/nlpeval.jl:35-41), called back from the engine once per
+# sweep on the thread that is inside the ccall.  Constraint checks, cuts and the LP stay on the device.
+mutable struct HostEval
+    d::MathProgBase.AbstractNLPEvaluator
+    num_var::Int
+    num_constr::Int
+    perm::Vector{Int}              # CSR entry k = COO entry perm[k]  (src/separators.jl:96-100)
+    jcoo::Vector{Float64}
+end
+
+# ktn_eval_rows_cb (include/katana_hip.h): g[num_constr], jac in the CSR order of the description
+function eval_rows_cb(user::Ptr{Void}, xp::Ptr{Cdouble}, gp::Ptr{Cdouble}, jp::Ptr{Cdouble})::Cint
+    try
+        h = unsafe_pointer_to_objref(user)::HostEval
+        x = copy(unsafe_wrap(Array, xp, h.num_var))
+        g = unsafe_wrap(Array, gp, h.num_constr)
+        MathProgBase.eval_jac_g(h.d, h.jcoo, x)                                 # src/separators.jl:112
+        MathProgBase.eval_g(h.d, g, x)                                          # src/separators.jl:113
+        jac = unsafe_wrap(Array, jp, length(h.perm))
+        for k in 1:length(h.perm)
+            jac[k] = h.jcoo[h.perm[k]]
+        end
+        return Cint(0)
+    catch
+        return Cint(1)                                                          # never unwind through the C ABI: KTN_E_CALLBACK
+    end
+end
+
+# ktn_eval_obj_cb: f and the dense gradient
+function eval_obj_cb(user::Ptr{Void}, xp::Ptr{Cdouble}, fp::Ptr{Cdouble}, gradp::Ptr{Cdouble})::Cint
+    try
+        h = unsafe_pointer_to_objref(user)::HostEval
+        x = copy(unsafe_wrap(Array, xp, h.num_var))
+        unsafe_store!(fp, MathProgBase.eval_f(h.d, x))                          # src/nlpeval.jl:35
+        MathProgBase.eval_grad_f(h.d, unsafe_wrap(Array, gradp, h.num_var), x)  # src/nlpeval.jl:36-39
+        return Cint(0)
+    catch
+        return Cint(1)
+    end
+end
+
+function build_host_nlp_desc(d::MathProgBase.AbstractNLPEvaluator, num_var::Int, num_constr::Int)
+    MathProgBase.initialize(d, [:Grad, :Jac])                                   # src/separators.jl:88
+    sp_rows, sp_cols = MathProgBase.jac_structure(d)
+    N = length(sp_rows)
+    counts = zeros(Int64, num_constr)
+    for ind in 1:N
+        counts[sp_rows[ind]] += 1
+    end
+    rowptr = zeros(Int64, num_constr + 1)
+    for i in 1:num_constr
+        rowptr[i + 1] = rowptr[i] + counts[i]
+    end
+    fill_pos = copy(rowptr[1:num_constr])
+    col = zeros(Int32, N)
+    perm = zeros(Int, N)
+    for ind in 1:N
+        i = sp_rows[ind]
+        fill_pos[i] += 1
+        col[fill_pos[i]] = Int32(sp_cols[ind] - 1)
+        perm[fill_pos[i]] = ind
+    end
+    row_linear = UInt8[MathProgBase.isconstrlinear(d, i) ? 1 : 0 for i in 1:num_constr]     # src/model.jl:116
+    arrs = NlpArrays(rowptr, col, perm, fill(KTN_ROW_HOST, num_constr), row_linear, zeros(Cdouble, num_constr),
+                     zeros(Int64, num_constr + 1), Int32[], Cdouble[], Int32[], Cdouble[])
+    host = HostEval(d, num_var, num_constr, perm, zeros(N))
+    rows_c = cfunction(eval_rows_cb, Cint, (Ptr{Void}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}))
+    obj_c = cfunction(eval_obj_cb, Cint, (Ptr{Void}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}))
+    desc = KtnNlpDesc(num_var, num_constr, pointer(arrs.rowptr), pointer(arrs.col),
+                      pointer(arrs.row_kind), pointer(arrs.row_linear), pointer(arrs.rconst),
+                      C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
+                      MathProgBase.isobjlinear(d) ? Int32(1) : Int32(0), Int32(KTN_ROW_HOST), 0, C_NULL, C_NULL, C_NULL, C_NULL,
+                      0.0, 0, C_NULL, C_NULL,
+                      rows_c, obj_c, pointer_from_objref(host))
+    return desc, arrs, host
+end
+
+# expressions when the evaluator offers them, callbacks otherwise
+function describe(d::MathProgBase.AbstractNLPEvaluator, num_var::Int, num_constr::Int)
+    if :ExprGraph in MathProgBase.features_available(d)
+        MathProgBase.initialize(d, [:Grad, :Jac, :ExprGraph])
+        desc, arrs = build_ktn_nlp_desc(d, num_var, num_constr)
+        return desc, arrs, nothing
+    end
+    return build_host_nlp_desc(d, num_var, num_constr)
+end
+
 # ---- the model type behind MathProgBase.NonlinearModel(s::KatanaSolver) ----------------------------------
 mutable struct KatanaHipModel <: MathProgBase.AbstractNonlinearModel
     handle::Ptr{Void}
     params::KtnParams
     arrays::Union{NlpArrays,Void}
+    host::Union{HostEval,Void}            # kept alive while the engine holds its address (eval_user)
 end
 
 function check(m::KatanaHipModel, code)
@@ -205,7 +304,7 @@ function KatanaHipModel(s)
     h = Ref{Ptr{Void}}(C_NULL)
     code = ccall((:ktn_create, LIB), Cint, (Ref{KtnParams}, Ref{Ptr{Void}}), Ref(prm), h)
     code == 0 || error("ktn_create failed ($code): no MI355X visible? the engine has no CPU path")
-    m = KatanaHipModel(h[], prm, nothing)
+    m = KatanaHipModel(h[], prm, nothing, nothing)
     finalizer(m, x -> ccall((:ktn_destroy, LIB), Void, (Ptr{Void},), x.handle))
     m
 end
@@ -213,9 +312,9 @@ end
 function MathProgBase.loadproblem!(m::KatanaHipModel, num_var::Int, num_constr::Int,
         l_var::Vector{Float64}, u_var::Vector{Float64}, l_constr::Vector{Float64}, u_constr::Vector{Float64},
         sense::Symbol, d::MathProgBase.AbstractNLPEvaluator)                                  # src/model.jl:81-86
-    MathProgBase.initialize(d, [:Grad, :Jac, :ExprGraph])
-    desc, arrs = build_ktn_nlp_desc(d, num_var, num_constr)
+    desc, arrs, host = describe(d, num_var, num_constr)       # tapes from :ExprGraph, else eval_g / eval_jac_g callbacks
     m.arrays = arrs
+    m.host = host
     check(m, ccall((:ktn_loadproblem, LIB), Cint,
         (Ptr{Void}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int32, Ref{KtnNlpDesc}),
         m.handle, num_var, num_constr, l_var, u_var, l_constr, u_constr, sense == :Max ? 1 : 0, Ref(desc)))
@@ -235,6 +334,65 @@ MathProgBase.getsolvetime(m::KatanaHipModel) = ccall((:ktn_get_solvetime, LIB), 
 MathProgBase.setwarmstart!(m::KatanaHipModel, x) = fill(0.0, length(x))                      # src/model.jl:335
 numiters(m::KatanaHipModel) = ccall((:ktn_numiters, LIB), Int64, (Ptr{Void},), m.handle)    # src/model.jl:326
 numcuts(m::KatanaHipModel)  = ccall((:ktn_numcuts,  LIB), Int64, (Ptr{Void},), m.handle)    # src/model.jl:333
+
+# ---- the two model factories of the reference, now returning the HIP model -------------------------------------
+MathProgBase.NonlinearModel(s::KatanaSolver) = KatanaHipModel(s)                                           # src/model.jl:63-65
+MathProgBase.LinearQuadraticModel(s::KatanaSolver) = MathProgBase.NonlinearToLPQPBridge(MathProgBase.NonlinearModel(s))   # src/solver.jl:46
+
+# ---- KatanaHipSeparator <: AbstractKatanaSeparator (src/separators.jl:8,23-53,58-120) ----------------------------
+# For users who keep the reference's loop and LP solver (KatanaSolver(GLPKSolverLP(), separator = KatanaHipSeparator())):
+# the separator plugin API served by the device.  initialize! loads the evaluator into an engine handle of its own;
+# precompute! is ONE evaluation sweep of all rows on the GPU (ktn_sep_precompute); isconstrsat / gencut then answer per
+# row from the device-resident g and J, like KatanaFirstOrderSeparator does from its host arrays.
+mutable struct KatanaHipSeparator <: AbstractKatanaSeparator
+    model::Union{KatanaHipModel,Void}
+    linear_model::Union{JuMP.Model,Void}
+    num_var::Int
+    num_constr::Int
+    cols::Vector{Int32}
+    coefs::Vector{Float64}
+    KatanaHipSeparator() = new(nothing, nothing, 0, 0, Int32[], Float64[])
+end
+
+function initialize!(sep::KatanaHipSeparator, linear_model::JuMP.Model, num_var::Int, num_constr::Int,
+                     oracle::MathProgBase.AbstractNLPEvaluator)                                            # src/separators.jl:81-107
+    sep.linear_model = linear_model
+    sep.num_var, sep.num_constr = num_var, num_constr
+    # the reference hands over its EpigraphNLPEvaluator when the objective is nonlinear (src/model.jl:166,171-172): the engine
+    # appends the row f(x) - t itself (src/nlpeval.jl:42-63), so the wrapped evaluator is what gets loaded
+    inner, nv, nc = isa(oracle, EpigraphNLPEvaluator) ? (oracle.nlpeval, num_var - 1, num_constr - 1) : (oracle, num_var, num_constr)
+    p = Ref{KtnParams}()
+    ccall((:ktn_default_params, LIB), Void, (Ref{KtnParams},), p)
+    h = Ref{Ptr{Void}}(C_NULL)
+    code = ccall((:ktn_create, LIB), Cint, (Ref{KtnParams}, Ref{Ptr{Void}}), p, h)
+    code == 0 || error("ktn_create failed ($code): no MI355X visible? the engine has no CPU path")
+    m = KatanaHipModel(h[], p[], nothing, nothing)
+    finalizer(m, x -> ccall((:ktn_destroy, LIB), Void, (Ptr{Void},), x.handle))
+    # bounds and sense play no part in the separator API (isconstrsat / gencut receive them per call): free variables,
+    # one-sided rows
+    MathProgBase.loadproblem!(m, nv, nc, fill(-Inf, nv), fill(Inf, nv), fill(-Inf, nc), zeros(nc), :Min, inner)
+    sep.model = m
+    kmax = ccall((:ktn_sep_jac_nnz, LIB), Int64, (Ptr{Void},), m.handle)
+    sep.cols, sep.coefs = zeros(Int32, kmax), zeros(kmax)
+end
+
+function precompute!(sep::KatanaHipSeparator, xstar)                                                       # src/separators.jl:111-116
+    x = convert(Vector{Float64}, xstar)
+    check(sep.model, ccall((:ktn_sep_precompute, LIB), Cint, (Ptr{Void}, Ptr{Cdouble}, Int64), sep.model.handle, x, length(x)))
+end
+
+isconstrsat(sep::KatanaHipSeparator, i, lb, ub, f_tol) =                                                   # src/separators.jl:120
+    check(sep.model, ccall((:ktn_sep_isconstrsat, LIB), Cint, (Ptr{Void}, Int64, Cdouble, Cdouble, Cdouble),
+                           sep.model.handle, i - 1, lb, ub, f_tol)) == 1
+
+function gencut(sep::KatanaHipSeparator, xstar, bounds, i)                                                 # src/separators.jl:118, src/algorithms.jl:3-18
+    nnz = Ref{Int64}(length(sep.cols))
+    b = Ref{Cdouble}(0.0)
+    check(sep.model, ccall((:ktn_sep_gencut, LIB), Cint, (Ptr{Void}, Int64, Ptr{Int32}, Ptr{Cdouble}, Ref{Int64}, Ref{Cdouble}),
+                           sep.model.handle, i - 1, sep.cols, sep.coefs, nnz, b))
+    v = JuMP.Variable[JuMP.Variable(sep.linear_model, Int(sep.cols[k]) + 1) for k in 1:nnz[]]
+    JuMP.AffExpr(v, sep.coefs[1:nnz[]], b[])
+end
 
 # ---- src/util.jl:16-36 ------------------------------------------------------------------------------------
 function getKatanaCuts(m::KatanaHipModel)

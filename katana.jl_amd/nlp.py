@@ -85,11 +85,10 @@ def SeparableNLP(inst):
     m = len(inst.rowptr) - 1
     rp = np.asarray(inst.rowptr)
     kind = np.ascontiguousarray(inst.kind, dtype=np.uint8)                       # a row is nonlinear iff one of its atoms is (LIN = 0)
-    if len(kind):
-        nonlin = np.maximum.reduceat(kind, np.minimum(rp[:-1], len(kind) - 1))
-        nonlin[np.diff(rp) == 0] = 0                                             # (reduceat returns an element for an empty slice)
-    else:
-        nonlin = np.zeros(m, dtype=np.uint8)
+    nonlin = np.zeros(m, dtype=np.uint8)
+    nz = np.flatnonzero(np.diff(rp) > 0)                                         # reduce over the non-empty rows only: reduceat
+    if len(nz):                                                                  # runs a slice up to the NEXT start, so an empty
+        nonlin[nz] = np.maximum.reduceat(kind, rp[:-1][nz])                      # row in between (or at the end) must not be a start
     return NLPDescription(
         inst.n, inst.rowptr, inst.col, np.zeros(m, dtype=np.uint8), (nonlin == 0).astype(np.uint8), inst.rconst,
         inst.kind, inst.p0, inst.p1,

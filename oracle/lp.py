@@ -32,9 +32,12 @@ def _new_highs(threads=1):
     h = _hc._Highs()
     h.setOptionValue("output_flag", bool(__import__("os").environ.get("KTN_ORACLE_LPLOG")))
     h.setOptionValue("solver", "simplex")
-    h.setOptionValue("simplex_strategy", 1)      # dual simplex, serial
-    if threads and int(threads) > 1:
-        h.setOptionValue("threads", int(threads))
+    if threads == 0:
+        pass                                     # HiGHS's own defaults: simplex strategy "choose", threads automatic
+    else:
+        h.setOptionValue("simplex_strategy", 1)  # dual simplex, serial
+        if int(threads) > 1:
+            h.setOptionValue("threads", int(threads))
     h.setOptionValue("primal_feasibility_tolerance", 1e-9)
     h.setOptionValue("dual_feasibility_tolerance", 1e-9)
     return h

@@ -271,6 +271,25 @@ for n in range(1, 21):
     m.con(sqrt(esum([v ** 2 for v in vs])), "<=", 1.0)
     m.expect(-n / math.sqrt(n), [1 / math.sqrt(n)] * n)
 
+# ---- extension of the test/misc.jl family beyond the reference's loop bound ----------
+# The reference runs `for n in 1:20` (test/misc.jl:6,35); the family has the closed form obj = -sqrt(n), x = 1/sqrt(n)
+# at every n.  These sizes are NOT among the reference's 82 tests: they exist so that the reference's tolerances are also
+# asserted on smooth-face optima with more LP columns than the exact small-LP kernel takes (32).  They go to their own file
+# (kat_family_ext.json); kat_models.json keeps exactly the reference's cases.
+N_REFERENCE = len(MODELS)
+for n in (33, 64, 128):
+    m = Model("501_01_n%d" % n, "test/misc.jl:4-30 (family, n beyond the reference's 1:20)")
+    vs = [m.var("x%d" % i) for i in range(n)]
+    m.objective("Min", esum([-v for v in vs]), True)
+    m.con(esum([v ** 2 for v in vs]), "<=", 1.0)
+    m.expect(-n / math.sqrt(n), [1 / math.sqrt(n)] * n)
+for n in (33, 64, 128):
+    m = Model("501_02_n%d" % n, "test/misc.jl:33-57 (family, n beyond the reference's 1:20)")
+    vs = [m.var("x%d" % i) for i in range(n)]
+    m.objective("Min", esum([-v for v in vs]), True)
+    m.con(sqrt(esum([v ** 2 for v in vs])), "<=", 1.0)
+    m.expect(-n / math.sqrt(n), [1 / math.sqrt(n)] * n)
+
 
 def _enc(o):
     if isinstance(o, float):
@@ -290,9 +309,14 @@ def _walk(o):
 
 
 if __name__ == "__main__":
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_models.json")
+    here = os.path.dirname(os.path.abspath(__file__))
+    tol = {"ref": "test/runtests.jl:16-20", "opt_atol": 1e-6, "opt_rtol": 1e-6, "sol_atol": 1e-3, "sol_rtol": 1e-3}
+    out = os.path.join(here, "kat_models.json")
     with open(out, "w") as f:
-        json.dump({"tolerances": {"ref": "test/runtests.jl:16-20", "opt_atol": 1e-6, "opt_rtol": 1e-6,
-                                  "sol_atol": 1e-3, "sol_rtol": 1e-3},
-                   "models": _walk(MODELS)}, f, indent=1)
-    print("wrote", out, len(MODELS), "models")
+        json.dump({"tolerances": tol, "models": _walk(MODELS[:N_REFERENCE])}, f, indent=1)
+    print("wrote", out, N_REFERENCE, "models")
+    out = os.path.join(here, "kat_family_ext.json")
+    with open(out, "w") as f:
+        json.dump({"tolerances": tol, "note": "closed-form members of the test/misc.jl family at sizes the reference does not run",
+                   "models": _walk(MODELS[N_REFERENCE:])}, f, indent=1)
+    print("wrote", out, len(MODELS) - N_REFERENCE, "models")

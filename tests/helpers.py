@@ -60,6 +60,17 @@ def planted_obj_bound(inst, f_tol=1e-6, lp_gap=1e-7):
     return f_tol * (lam + 0.6 * inst.meta["mu_sum"]) + lp_gap * (1.0 + 2.0 * abs(inst.opt_obj))
 
 
+def assert_planted_objective(obj, inst, f_tol=1e-6):
+    """The objective assertions of every planted-optimum test, in this order:
+    (1) the reference's own acceptance test, isapprox(obj, expected; atol = rtol = 1e-6) (test/runtests.jl:16-17, test/2d.jl:19),
+        with the planted optimum as the expected value;
+    (2) the per-instance Lagrangian bound of planted_obj_bound -- looser than (1) on the large configurations (its
+        0.6 sum(mu) f_tol term dominates), kept because it is what the stop rule guarantees a priori."""
+    tol = max(1e-6, 1e-6 * max(abs(obj), abs(inst.opt_obj)))
+    assert abs(obj - inst.opt_obj) <= tol, ("reference tolerance 1e-6/1e-6", obj, inst.opt_obj, abs(obj - inst.opt_obj), tol)
+    assert abs(obj - inst.opt_obj) <= planted_obj_bound(inst, f_tol=f_tol), ("planted bound", obj, inst.opt_obj)
+
+
 def max_nl_violation(inst, x):
     """max over NL rows of g_i(x) - ub_i under the oracle's evaluator"""
     d = oracle_evaluator(inst)

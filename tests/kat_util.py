@@ -24,6 +24,12 @@ def load_kats():
         return _dec(json.load(f))["models"]
 
 
+def load_family_ext():
+    """members of the test/misc.jl family at sizes the reference does not run (closed-form expectations; make_kat_fixture.py)"""
+    with open(os.path.join(HERE, "golden", "kat_family_ext.json")) as f:
+        return _dec(json.load(f))["models"]
+
+
 def isapprox(a, b, atol, rtol):
     """Julia's isapprox(a, b; atol, rtol): |a-b| <= max(atol, rtol*max(|a|,|b|))."""
     return abs(a - b) <= max(atol, rtol * max(abs(a), abs(b)))

@@ -134,3 +134,15 @@ def test_binding_structs_have_the_library_layout():
     L.lib().ktn_default_params(C.byref(p))
     # the last fields of the struct read back their documented defaults: the mirror is aligned end to end
     assert (p.f_tol, p.iter_cap, p.purge_min_rows, p.lp_dense_after, p.cut_cap_factor, p.cut_cap_min, p.lp_stag_factor) == (1e-6, 10000, 2000, 5000, 1.0, 10000, 100.0)
+
+
+def test_host_side_address_sanitizer_harness_of_the_abi_layer():
+    """`make asan` (katana.jl_amd/csrc/Makefile): the host code of the library built with -fsanitize=address, tests/c/ktn_abi_asan.c
+    linked against it and run here on the CPU box -- parameter defaults, handle creation and its failure path, every entry
+    point with NULL handles / outputs.  Any sanitizer report (or a leak of the failed ktn_create) fails the target.
+    (~80 s for the instrumented compile.  CPU tier only: the GPU pool refuses sanitizer runs.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "katana.jl_amd", "csrc"), "asan"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "ok (0 failures)" in r.stdout and "AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr

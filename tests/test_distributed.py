@@ -373,6 +373,38 @@ def test_two_rank_row_sharded_lp_through_the_tiled_copies():
     assert max_nl_violation(inst, out[0][3]) <= 1e-6 * (1 + 1e-6)
 
 
+def _worker_rowshard_few_nl(rank, world, port, out, inst_kw):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import katana_jl_amd as ktn
+    from katana_jl_amd.distributed import RowShardedKatanaModel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    inst = ktn.instances.make_instance(**inst_kw)
+    m = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0), inst, rank, world, dist)
+    status = m.optimize()
+    out[rank] = (status, m.getobjval(), m.getsolution(), m.numiters(), m.m.stat("allreduce_calls"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_row_sharded_solve_with_fewer_nl_rows_than_ranks():
+    """ONE nonlinear row on two ranks: one rank's shard has no NL row at all.  Its LP tolerances -- and with them its restart
+    and exit decisions, i.e. the sequence of collectives -- must still be those of the other rank (the pure-LP rule of
+    Engine::step is taken from the all-reduced NL-row count); both ranks end with the same x at the planted optimum."""
+    import katana_jl_amd as ktn
+    from helpers import max_nl_violation, planted_obj_bound
+    world = 2
+    inst_kw = dict(n=200, m_nl=1, k=8, family="explog", seed=5)
+    out = mp.Manager().dict()
+    mp.spawn(_worker_rowshard_few_nl, args=(world, _free_port(), out, inst_kw), nprocs=world, join=True)
+    inst = ktn.instances.make_instance(**inst_kw)
+    assert out[0][0] == out[1][0] == "Optimal"
+    assert out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]
+    assert out[0][4] == out[1][4] > 0                                   # the same number of all-reduces on both ranks
+    assert abs(out[0][1] - inst.opt_obj) <= planted_obj_bound(inst)
+    assert max_nl_violation(inst, out[0][2]) <= 1e-6 * (1 + 1e-6)
+
+
 def _worker_rccl_one_rank(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ["KTN_FORCE_COLLECTIVE"] = "1"

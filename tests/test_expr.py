@@ -96,3 +96,20 @@ def test_fuse_instances_is_block_diagonal():
     first_nl_b = rp[f.m_lin + a.m_nl]
     assert np.array_equal(f.col[first_nl_b:], b.col[lb:] + 50) and np.array_equal(f.p0[first_nl_b:], b.p0[lb:])
     assert np.all(f.col[rp[f.m_lin]:first_nl_b] < 50)
+
+
+def test_row_linearity_with_empty_rows_in_between_and_at_the_end():
+    """SeparableNLP: a row is nonlinear iff one of its atoms is; empty rows (interior or trailing) are linear and must not
+    cut the preceding row's reduction short (rp = [0,2,4,4], kinds [0,0,0,2]: row 1 IS nonlinear)."""
+    from types import SimpleNamespace
+    from katana_jl_amd.nlp import SeparableNLP
+    inst = SimpleNamespace(n=3, rowptr=np.array([0, 2, 2, 4, 4, 4], dtype=np.int64), col=np.array([0, 1, 1, 2], dtype=np.int32),
+                           kind=np.array([0, 0, 0, 2], dtype=np.uint8), p0=np.ones(4), p1=np.zeros(4), rconst=np.zeros(5),
+                           obj_col=np.array([0], dtype=np.int32), obj_kind=np.array([0], dtype=np.uint8), obj_p0=np.ones(1),
+                           obj_p1=np.zeros(1), obj_const=0.0)
+    d = SeparableNLP(inst)
+    assert list(d.row_linear) == [1, 1, 0, 1, 1]
+    inst.rowptr = np.array([0, 2, 4, 4], dtype=np.int64); inst.rconst = np.zeros(3)
+    assert list(SeparableNLP(inst).row_linear) == [1, 0, 1]
+    inst.kind = np.array([3, 0, 0, 0], dtype=np.uint8)
+    assert list(SeparableNLP(inst).row_linear) == [0, 1, 1]

@@ -123,3 +123,80 @@ def test_coo_to_csr_conversion_matches_initialize():
     assert [list(col[rowptr[i]:rowptr[i + 1]]) for i in range(m)] == sp_cols
     order = np.argsort(rows, kind="stable")                       # what nlp.CallbackNLP uses
     assert np.array_equal(order, perm)
+
+
+def _code_only(src):
+    """Julia source without comments, string literals and the inside of [...] (where `end` is an index, not a block end)"""
+    out = []
+    for line in src.splitlines():
+        line = re.sub(r'"(?:[^"\\]|\\.)*"', '""', line)
+        line = line.split("#", 1)[0]
+        prev = None
+        while prev != line:
+            prev = line
+            line = re.sub(r"\[[^\[\]]*\]", "", line)
+        out.append(line)
+    return "\n".join(out)
+
+
+def test_blocks_are_balanced():
+    """no julia here to parse the file: at least every block opener has its `end`"""
+    code = _code_only(JL)
+    openers = len(re.findall(r"(?m)^\s*(?:mutable struct|struct|module|function|if|for|while|try|let|begin)\b", code))
+    openers += len(re.findall(r"\bdo\b", code))
+    ends = len(re.findall(r"\bend\b", code))
+    assert openers == ends, (openers, ends)
+    assert code.count("(") == code.count(")")
+
+
+def test_every_plugin_method_of_the_reference_has_a_method_here():
+    """src/model.jl:63-65,81-86,219,326-343 and src/solver.jl:46: the MathProgBase methods (and numiters / numcuts) the reference
+    defines on its model, and the two model factories on KatanaSolver"""
+    for name in ("loadproblem!", "optimize!", "setwarmstart!", "status", "getobjval", "getsolution", "getsolvetime"):
+        assert re.search(r"MathProgBase\.%s\(m::KatanaHipModel" % re.escape(name), JL), name
+    for name in ("numiters", "numcuts"):
+        assert re.search(r"(?m)^%s\(m::KatanaHipModel\)" % name, JL), name
+    assert re.search(r"(?m)^MathProgBase\.NonlinearModel\(s::KatanaSolver\) = KatanaHipModel\(s\)", JL)
+    assert re.search(r"(?m)^MathProgBase\.LinearQuadraticModel\(s::KatanaSolver\) = MathProgBase\.NonlinearToLPQPBridge\(MathProgBase\.NonlinearModel\(s\)\)", JL)
+    assert "import ..KatanaSolver, ..AbstractKatanaSeparator, ..EpigraphNLPEvaluator" in JL
+    # the loadproblem! signature is the reference's (src/model.jl:81-86)
+    sig = re.search(r"function MathProgBase\.loadproblem!\(m::KatanaHipModel,(.*?)\)\s+#", JL, re.S).group(1)
+    assert [t.strip() for t in re.findall(r"::([\w.{}]+)", sig)] == ["Int", "Int", "Vector{Float64}", "Vector{Float64}", "Vector{Float64}",
+                                                                       "Vector{Float64}", "Symbol", "MathProgBase.AbstractNLPEvaluator"]
+
+
+def test_separator_plugin_api_is_implemented_over_the_sep_entry_points():
+    """src/separators.jl:8,23-53: a subtype of AbstractKatanaSeparator with the four API methods, each over its ktn_sep_* call"""
+    assert re.search(r"mutable struct KatanaHipSeparator <: AbstractKatanaSeparator", JL)
+    assert "import ..initialize!, ..precompute!, ..gencut, ..isconstrsat" in JL
+    body = JL[JL.index("mutable struct KatanaHipSeparator"):JL.index("# ---- src/util.jl")]
+    for method, sym in (("initialize!", "ktn_sep_jac_nnz"), ("precompute!", "ktn_sep_precompute"), ("isconstrsat", "ktn_sep_isconstrsat"),
+                        ("gencut", "ktn_sep_gencut")):
+        m = re.search(r"(?ms)^(?:function )?%s\(sep::KatanaHipSeparator.*?(?=^(?:function |isconstrsat\(|# ----)|\Z)" % re.escape(method), body)
+        assert m and sym in m.group(0), (method, sym)
+    # initialize! has the reference's signature (src/separators.jl:81-85) and unwraps the epigraph evaluator the reference passes
+    assert re.search(r"initialize!\(sep::KatanaHipSeparator, linear_model::JuMP\.Model, num_var::Int, num_constr::Int,\s+oracle::MathProgBase\.AbstractNLPEvaluator\)", JL)
+    assert "isa(oracle, EpigraphNLPEvaluator)" in JL and "oracle.nlpeval" in JL
+    # gencut returns what linear_oa_cut returns: AffExpr over JuMP.Variable(linear_model, col) (src/algorithms.jl:6-17), 1-based columns
+    assert "JuMP.Variable(sep.linear_model, Int(sep.cols[k]) + 1)" in body and "JuMP.AffExpr(v, sep.coefs[1:nnz[]], b[])" in body
+    assert "i - 1" in body                                   # 1-based row of the plugin API -> 0-based row of the ABI
+
+
+def test_host_callback_path_matches_the_header_typedefs():
+    """no :ExprGraph -> KTN_ROW_HOST rows with cfunction trampolines of the two callback types of include/katana_hip.h"""
+    for cb in ("ktn_eval_rows_cb", "ktn_eval_obj_cb"):
+        m = re.search(r"typedef int \(\*%s\)\(void\* user, const double\* x, double\* \w+, double\* \w+\);" % cb, HDR)
+        assert m, cb
+    assert len(re.findall(r"cfunction\(eval_(?:rows|obj)_cb, Cint, \(Ptr\{Void\}, Ptr\{Cdouble\}, Ptr\{Cdouble\}, Ptr\{Cdouble\}\)\)", JL)) == 2
+    assert ":ExprGraph in MathProgBase.features_available(d)" in JL
+    host = JL[JL.index("function build_host_nlp_desc"):JL.index("# expressions when the evaluator offers them")]
+    assert "fill(KTN_ROW_HOST, num_constr)" in host and "Int32(KTN_ROW_HOST)" in host and "pointer_from_objref(host)" in host
+    assert "rows_c, obj_c, pointer_from_objref(host))" in host          # eval_rows, eval_obj, eval_user: the last three fields of KtnNlpDesc
+    assert [f for f, _ in julia_struct_fields("KtnNlpDesc")][-3:] == ["eval_rows", "eval_obj", "eval_user"]
+    # the callbacks use exactly the evaluator calls the reference makes (src/separators.jl:112-113, src/nlpeval.jl:35-39) and never throw
+    cbs = JL[JL.index("function eval_rows_cb"):JL.index("function build_host_nlp_desc")]
+    for call in ("MathProgBase.eval_jac_g(h.d, h.jcoo, x)", "MathProgBase.eval_g(h.d, g, x)", "MathProgBase.eval_f(h.d, x)", "MathProgBase.eval_grad_f(h.d,"):
+        assert call in cbs, call
+    assert cbs.count("catch") == 2 and cbs.count("return Cint(1)") == 2
+    # KatanaHipModel keeps the HostEval object alive (its address is the engine's eval_user)
+    assert "m.host = host" in JL and re.search(r"host::Union\{HostEval,Void\}", JL)

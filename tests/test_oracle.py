@@ -5,7 +5,7 @@ import pytest
 
 import katana_jl_amd as ktn
 from helpers import TRAJECTORY_SENSITIVE, oracle_solve_instance, oracle_solve_kat
-from kat_util import isapprox, load_kats
+from kat_util import isapprox, load_family_ext, load_kats
 
 KATS = load_kats()
 # the n-D sphere family is exercised at every second size on the CPU tier to keep it quick
@@ -35,6 +35,22 @@ def test_oracle_passes_reference_kat(m):
         if e["x"] is not None:
             for got, want in zip(x, e["x"]):
                 assert isapprox(got, want, e["sol_atol"], e["sol_rtol"]), (list(x), e["x"])
+
+
+def test_oracle_on_the_ball_family_beyond_the_reference_sizes():
+    """tests/golden/kat_family_ext.json: the smallest member (n = 33, quadratic form) through the oracle -- 2 711 ECP iterations
+    on HiGHS vertices, 20 s; the larger ones and the norm form (10 000 iterations without meeting the stop rule on exact
+    vertices) are pinned by their closed form only."""
+    ext = {m["id"]: m for m in load_family_ext()}
+    assert sorted(ext) == sorted("501_0%d_n%d" % (f, n) for f in (1, 2) for n in (33, 64, 128))
+    for m in ext.values():
+        n = len(m["vars"])
+        assert abs(m["expect"]["obj"] + np.sqrt(n)) < 1e-12 and np.allclose(m["expect"]["x"], 1 / np.sqrt(n), rtol=0, atol=1e-15)
+    m = ext["501_01_n33"]
+    om = oracle_solve_kat(m)
+    assert om.getstatus() == "Optimal"
+    assert isapprox(om.getobjval(), m["expect"]["obj"], 1e-6, 1e-6)
+    assert np.max(np.abs(np.asarray(om.getsolution()[:33]) - m["expect"]["x"])) <= 1e-3
 
 
 def test_fast_path_equals_literal_path():
