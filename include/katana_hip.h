@@ -157,6 +157,12 @@ typedef struct {
        is measured from the NEWEST cut, t = s + grad f(x_k)'x + b_k: the cuts' common part moves into the cost vector and the rows
        keep only their differences (csrc/kernels.hpp "epigraph reference shift").  The LP that getKatanaCuts exports is unchanged. */
     int32_t epi_shift;      /* 1       0 = solve the LP in the reference's own form                                              */
+    /* objective certificate (problems with more than polish_max_var LP columns): at the point that meets the stop rule the engine
+       evaluates  sum_i lambda_i (signed residual of NL row i) -- the convexity bound on  f* - objective  with the LP's duals as
+       multipliers -- and keeps cutting below f_tol (at most polish_max_iter passes, not counted in numiters) while it exceeds
+       obj_cert_tol * max(1, |objective|).  The reference's tests accept an objective within 1e-6 (test/runtests.jl:16-17); its exact
+       simplex vertices end Kelley's method far below f_tol, a first-order LP ends AT f_tol times the multipliers.              */
+    double  obj_cert_tol;   /* 1e-6    (refines while the sum exceeds half of it)  0 = stop at the reference's rule alone          */
 } ktn_params;
 
 /* The device-evaluable statement of the NLP: replaces the

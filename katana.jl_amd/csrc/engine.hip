@@ -151,6 +151,7 @@ struct LpResult {
     int status = KTN_STATUS_NONE;   // OPTIMAL / USERLIMIT
     int64_t iters = 0;
     double pobj = 0.0, dobj = 0.0, row_viol = 0.0, gap = 0.0;
+    double dres_rel = 0.0;          // dual residual over (1 + ||c||): what the solve's gap tolerance is compared with
     bool exact = false;             // solved by the exact small-LP kernel: no tolerance tightening needed
 };
 
@@ -342,6 +343,10 @@ struct Engine {
     // cutting at polish_factor * f_tol; the point returned is the best one that satisfies the reference's rule
     bool polishing = false, polish_done = false;
     int polish_count = 0;
+    double polish_phi = 1e-3;       // the refinement cuts rows beyond polish_phi * f_tol
+    double cert_target = 0.0;       // > 0: certificate-driven refinement (kernels.hpp "objective certificate"), ends when met
+    DBuf<double> d_cert;
+    double objective_certificate();
     double best_viol = kInf, best_obj = 0.0;
     DBuf<double> d_xbest;
     // print_header / print_stats bookkeeping  src/model.jl:209-217,252-254,284-303
@@ -1260,7 +1265,7 @@ void Engine::reset() {
     iter = 0; soltime = 0.0; objval = std::numeric_limits<double>::quiet_NaN();
     last_maxviol = 1e300; obj_prev = kInf; allsat = false; begun = false; tight_done = false;
     log_cuts_lastprnt = 0; log_max_viol = 0; purged_total = 0;
-    polishing = false; polish_done = false; polish_count = 0; best_viol = kInf; best_obj = 0.0;
+    polishing = false; polish_done = false; polish_count = 0; best_viol = kInf; best_obj = 0.0; cert_target = 0.0;
     lp_sols.clear();
     sync();
 }
@@ -2150,7 +2155,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     const int chk = std::max(1, prm.lp_check_every);
     const int plain_len = std::min(chk - 1, (int)kMaxChunk);
     static const int first_chunk = std::getenv("KTN_FIRST_CHUNK") ? std::atoi(std::getenv("KTN_FIRST_CHUNK")) : 31;
-    bool plain_next = false, near_conv = false;
+    bool plain_next = false, near_conv = false, primal_ok = false;
+    static const int stag_chunk = std::getenv("KTN_STAG_CHUNK") ? std::atoi(std::getenv("KTN_STAG_CHUNK")) : 0;
     // throughput mode: one workgroup per block runs its LP to the end (batch_lp.hpp); the ordinary loop below only serves
     // as the fall-back when a block reports that it could not finish
     bool blocks_done = false;
@@ -2171,6 +2177,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             int want = (k <= 1 && first_chunk > 0) ? std::min(first_chunk, plain_len) : plain_len;
             // close to the tolerances the next check comes sooner: a solve ends on average half a chunk after it converged
             if (near_conv && near_chunk > 0) want = std::min(want, near_chunk);
+            if (primal_ok && stag_chunk > 0 && mode == 0) want = std::min(want, stag_chunk);
             const int np = (int)std::min<int64_t>(want, max_it - it);
             if (np <= 0) continue;
             for (int j = 0; j < np; ++j) {
@@ -2212,8 +2219,10 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         if (dbg_lp) std::fprintf(stderr, "[lp mode %d] it %7lld k %6lld r %.3e pviol %.3e dres %.3e gap %.3e pobj %.10g dobj %.10g om %.3g eta %.3g\n",
                                  mode, (long long)it, (long long)k, r, pviol, dres, gap, pobj, dobj, om, eta);
         R.pobj = pobj; R.dobj = dobj; R.row_viol = pviol; R.gap = gap;
+        R.dres_rel = dres * cinf_scale / (1.0 + std::sqrt(nc2_tol));
         bool done = (pviol <= tol_p) && (gap <= tol_g) && (dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2_tol)));
         near_conv = (pviol <= 4.0 * tol_p) && (gap <= 4.0 * tol_g) && (dres * cinf_scale <= 4.0 * tol_g * (1.0 + std::sqrt(nc2_tol)));
+        primal_ok = (pviol <= tol_p) && (dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2_tol)));
         // Primal-stagnation exit (lp_stag_factor).  On LPs with degenerate duals the primal part converges within a few
         // hundred iterations while the duality gap crawls for 10 000 more: stop when the rows are
         // feasible to tol_p, the dual residual is converged, the primal objective has not moved by more than 0.1 tol_g
@@ -2521,9 +2530,12 @@ void Engine::step(int32_t* done) {
     last_maxviol = mv;
     const bool sat_now = (nviol == 0);
     // inexact-LP rule (DESIGN.md "LP tolerance schedule"): all rows satisfied only counts once
-    // the LP itself was solved to the floor tolerance
-    if (sat_now && !R.exact && tol_p > floor_p * (1.0 + 1e-12)) last_maxviol = 0.0;
-    else allsat = sat_now;
+    // the LP itself was solved to the floor tolerance -- by request, or because the last check of a looser solve
+    // happens to meet the floor tolerances already (then the re-solve would return this very point)
+    const double floor_g = std::min(std::max(floor_p, prm.lp_gap_floor), prm.lp_gap_cap);
+    const bool at_floor = R.row_viol <= floor_p && R.gap <= floor_g && R.dres_rel <= floor_g;
+    if (sat_now && !R.exact && tol_p > floor_p * (1.0 + 1e-12) && !at_floor) last_maxviol = 0.0;
+    else { allsat = sat_now; if (sat_now && tol_p > floor_p * (1.0 + 1e-12) && !R.exact) stats["floor_resolves_skipped"] += 1.0; }
     const double obj = objval;                                           // model.jl:287-289
     const double obj_delta = std::fabs((obj_prev - obj) / obj);
     obj_prev = obj;
@@ -2547,8 +2559,28 @@ void Engine::step(int32_t* done) {
     *done = (allsat || iter >= prm.iter_cap) ? 1 : 0;
     // Terminal refinement of small problems: the reference's simplex vertices end Kelley's method with the last
     // violation far below f_tol (its tests ask the objective to 1e-6 / 1e-7); a first-order LP ends AT f_tol.
-    if (allsat && !eps_stop && !polish_done && !sharded_rows && !row_sharded() && prm.polish_factor > 0.0 && prm.polish_factor < 1.0 &&
-        prm.polish_max_iter > 0 && n_lp <= prm.polish_max_var && m_nl > 0) {
+    bool refine = false;
+    if (allsat && !eps_stop && !polish_done && !sharded_rows && !row_sharded() && prm.polish_max_iter > 0 && m_nl > 0) {
+        if (n_lp <= prm.polish_max_var) {
+            refine = prm.polish_factor > 0.0 && prm.polish_factor < 1.0;
+            polish_phi = prm.polish_factor;
+            cert_target = 0.0;
+        } else if (prm.obj_cert_tol > 0.0 && lists_ok() && n_blocks == 0) {
+            // Larger problems: refine only while the multiplier-weighted residual of the NL rows (the part of  f* - objective  the
+            // stop rule leaves open; the LP's own accuracy is its gap tolerance) exceeds half the objective tolerance
+            const double target = prm.obj_cert_tol * std::max(1.0, std::fabs(objval));
+            const double D = objective_certificate();
+            stats["cert_evals"] += 1.0;
+            stats["cert_last"] = D;
+            if (D > 0.5 * target) {
+                refine = true;
+                cert_target = target;
+                polish_phi = std::min(std::max(0.25 * target / D, 0.05), 0.5);
+                stats["cert_refinements"] += 1.0;
+            }
+        }
+    }
+    if (refine) {
         polishing = true;
         polish_count = 0;
         best_viol = kInf;
@@ -2563,7 +2595,7 @@ void Engine::step(int32_t* done) {
 // Ends when no such row is left, or after polish_max_iter passes; the answer is then the point with the smallest violation
 // among those that satisfy the reference's stop rule (every row within f_tol).
 void Engine::polish_step(int32_t* done) {
-    const double f_eff = prm.polish_factor * prm.f_tol;
+    const double f_eff = polish_phi * prm.f_tol;
     int64_t nviol = 0;
     double mv = 0.0;
     bool nonfin = false;
@@ -2591,20 +2623,43 @@ void Engine::polish_step(int32_t* done) {
         if (nonfin) { status = KTN_STATUS_ERROR; polishing = false; *done = 1; return; }
         consider(mv);
         polish_count = 1;
-        if (nviol == 0) finish();
+        if (nviol == 0 && cert_target <= 0.0) finish();     // (certificate mode: the LP itself may be what is short -- solve it tighter)
         return;
     }
     if (polish_count > prm.polish_max_iter) { finish(); return; }
     ++polish_count;
     stats["polish_iters"] += 1.0;
     const double tol_p = prm.lp_tol_floor * f_eff;
-    const double tol_g = std::max(prm.lp_gap_floor * prm.polish_factor, 1e-12);
+    // gap tolerance of a refinement solve: scaled with the cut tolerance (small problems); in certificate mode a quarter of the
+    // objective tolerance, as a relative gap
+    const double tol_g = cert_target > 0.0 ? std::min(std::min(std::max(tol_p, prm.lp_gap_floor), prm.lp_gap_cap), 0.25 * cert_target / (1.0 + 2.0 * std::fabs(objval)))
+                                           : std::max(prm.lp_gap_floor * polish_phi, 1e-12);
     LpResult R = lp_solve(tol_p, tol_g, 0);
     if (R.status != KTN_STATUS_OPTIMAL) { finish(); return; }            // keep the point that met the stop rule
     sweep(lp_x.p, f_eff, &nviol, &mv, &nonfin);
     if (nonfin) { finish(); return; }
     consider(mv);
+    if (cert_target > 0.0 && mv <= prm.f_tol) {                          // certificate mode: done as soon as the bound holds
+        const double D = objective_certificate();
+        stats["cert_evals"] += 1.0;
+        stats["cert_last"] = D;
+        if (D <= 0.5 * cert_target) { finish(); return; }
+    }
     if (nviol == 0) finish();
+}
+
+// max(sum_i lambda_i res_i, 0) over the NL rows at (lp_x, lp_y), with g of the last sweep (kernels.hpp "objective certificate")
+double Engine::objective_certificate() {
+    if (m_nl <= 0) return 0.0;
+    d_cert.resize((size_t)m_nl, stream);
+    LAUNCH_1(k_cert_nl, m_nl, stream, m_nl, d_nlrows.p, list_heads(), d_cutprev.p, lp_y.p, d_g.p, d_lb.p, d_ub.p, prm.f_tol, d_cert.p);
+    hipLaunchKernelGGL(k_sum_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, m_nl, d_cert.p, partials.p);
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, d_scal.p);
+    check_launch();
+    double D = 0.0;
+    KTN_HIP(hipMemcpyAsync(&D, d_scal.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    return (D == D) ? std::max(D, 0.0) : kInf;
 }
 
 void Engine::end() {
@@ -2661,6 +2716,7 @@ void ktn_default_params(ktn_params* p) {
     p->lp_ruiz_warm = 0; p->lp_tiled_nnz = 4000000; p->lp_near_check = 7; p->dedupe_eps = 1e-6;
     p->polish_factor = 1e-3; p->polish_max_var = 32; p->polish_max_iter = 30;
     p->epi_shift = 1;
+    p->obj_cert_tol = 1e-6;
 }
 
 int ktn_create(const ktn_params* p, ktn_handle* out) {

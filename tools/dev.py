@@ -82,7 +82,7 @@ def cmd_steps(ktn, args):
 def cmd_seeds(ktn, args):
     import numpy as np
     name, n0, n1, kw = args[0], int(args[1]), int(args[2]), _opts(args[3:])
-    ws, errs, its, tot_p = [], [], [], 0
+    ws, errs, its, tot_p, refine = [], [], [], 0, 0
     for seed in range(n0, n1):
         inst = _make(ktn, name, seed)
         m = _load(ktn, inst, log_level=0, **kw)
@@ -91,9 +91,10 @@ def cmd_seeds(ktn, args):
         t = time.time(); st = m.optimize(); w = time.time() - t
         assert st == "Optimal", (seed, st)
         ws.append(w); tot_p += m.stat("pdhg_iters") - p0; errs.append(_relerr(m, inst)); its.append(m.numiters())
+        refine += int(m.stat("cert_refinements") > 1)          # (two solves per seed: > 1 = the timed one refined too)
         print("  seed %d: %s %.3fs iters %d relerr %.1e" % (seed, st, w, m.numiters(), errs[-1]), flush=True)
-    print("%s seeds %d-%d %s: mean %.3fs median %.3fs max %.3fs total pdhg %d ecp iters %s max relerr %.1e | %s" % (
-        name, n0, n1 - 1, kw, np.mean(ws), np.median(ws), np.max(ws), tot_p, its, max(errs), " ".join("%.3f" % w for w in ws)))
+    print("%s seeds %d-%d %s: mean %.3fs median %.3fs max %.3fs total pdhg %d refined %d ecp iters %s max relerr %.1e | %s" % (
+        name, n0, n1 - 1, kw, np.mean(ws), np.median(ws), np.max(ws), tot_p, refine, its, max(errs), " ".join("%.3f" % w for w in ws)))
 
 
 def cmd_knobs(ktn, args):
