@@ -248,6 +248,14 @@ struct Engine {
     DBuf<int64_t> c_ptr, c_cnt;
     DBuf<int32_t> c_row;
     DBuf<double> c_val, c_sval, r_sval;
+    // per mirror position the CSR entry it came from; rows / entries the mirror covers; `lp_epoch` counts the changes that are
+    // NOT appends (reset, purge, truncate) -- while it stands still the mirror is extended by a merge instead of a sort
+    DBuf<uint32_t> c_perm, c_perm2;
+    DBuf<int32_t> c_row2;
+    DBuf<int64_t> c_ptr2, c_off;
+    int64_t csc_M = -1, csc_NNZ = 0;
+    uint64_t lp_epoch = 1, csc_epoch = 0;
+    void csc_merge_appended();
     // Working form of the LP during a first-order solve with a nonlinear objective: the epigraph cuts relative to the newest one
     // (kernels.hpp "epigraph reference shift").  The stored LP keeps the reference's form; w_shift says that the CSC mirror,
     // the scaling and the w* arrays currently hold the shifted problem.
@@ -710,7 +718,8 @@ struct Engine {
         for (DBuf<int64_t>* b : {&lp_rowptr, &lp_rowptr2, &d_cutprev, &d_cutprev2, &d_keep, &d_keepnnz, &d_newidx, &d_newptr}) b->reserve(r, stream);
         for (DBuf<int32_t>* b : {&d_age, &d_age2, &d_longrows}) b->reserve(r, stream);
         for (DBuf<double>* b : {&lp_val, &lp_val2, &c_val, &c_sval, &r_sval}) b->reserve(z, stream);
-        for (DBuf<int32_t>* b : {&lp_col, &lp_col2, &c_row}) b->reserve(z, stream);
+        for (DBuf<int32_t>* b : {&lp_col, &lp_col2, &c_row, &c_row2}) b->reserve(z, stream);
+        c_perm.reserve(z, stream); c_perm2.reserve(z, stream);
         k_in.reserve(z, stream); k_out.reserve(z, stream); p_in.reserve(z, stream); p_out.reserve(z, stream);
         // per-solve scratch that would otherwise grow (hipMalloc + copy + hipFree, a device synchronisation each) while the
         // first solve runs: packed row records, check partials (at most rows / 4 + columns / 4 blocks), sort / scan storage
@@ -1253,7 +1262,7 @@ void Engine::reset() {
     d_lastcut.upload(neg1, stream);
     d_age.resize((size_t)std::max<int64_t>(M, 1), stream);
     d_age.zero(stream);
-    lp_dirty = true; ++lp_version; have_omega = false; have_precompute = false; sharded_rows = false; scal_rows = 0; smax_rows = 0;
+    lp_dirty = true; ++lp_version; ++lp_epoch; have_omega = false; have_precompute = false; sharded_rows = false; scal_rows = 0; smax_rows = 0;
     blocks_built_rows = -1;
     if (d_blkomega.n) d_blkomega.zero(stream);
     if (ds_valid.n) ds_valid.zero(stream);
@@ -1274,32 +1283,62 @@ void Engine::reset() {
 // LP: column mirror, scaling, PDHG
 // ------------------------------------------------------------------------------------
 void Engine::rebuild_csc() {
-    c_ptr.resize((size_t)n_lp + 1, stream);
-    c_cnt.resize((size_t)n_lp + 1, stream);
-    c_cnt.zero(stream);
-    c_row.resize((size_t)NNZ + 1, stream);
+    const bool no_merge = std::getenv("KTN_NO_CSC_MERGE") != nullptr;       // (tests: the sort path for every solve)
     c_val.resize((size_t)NNZ + 1, stream);
-    if (NNZ > 0) {
-        k_in.resize((size_t)NNZ, stream); k_out.resize((size_t)NNZ, stream);
-        p_in.resize((size_t)NNZ, stream); p_out.resize((size_t)NNZ, stream);
-        LAUNCH_G(pick_group((double)NNZ / (double)std::max<int64_t>(M, 1)), k_csc_keys, M, stream, M, lp_rowptr.p, lp_col.p, k_in.p,
-                 p_in.p, c_cnt.p);
-        check_launch();
+    if (!no_merge && csc_epoch == lp_epoch && csc_M >= 0 && M >= csc_M && NNZ >= csc_NNZ && NNZ < ((int64_t)1 << 32)) {
+        if (M > csc_M) csc_merge_appended();              // (M == csc_M: same structure, only the values are gathered again)
+        stats["lp_csc_merges"] += 1.0;
+    } else {
+        c_ptr.resize((size_t)n_lp + 1, stream);
+        c_cnt.resize((size_t)n_lp + 1, stream);
+        c_cnt.zero(stream);
+        c_row.resize((size_t)NNZ + 1, stream);
+        c_perm.resize((size_t)NNZ + 1, stream);
+        if (NNZ > 0) {
+            k_in.resize((size_t)NNZ, stream); k_out.resize((size_t)NNZ, stream);
+            p_in.resize((size_t)NNZ, stream); p_out.resize((size_t)NNZ, stream);
+            LAUNCH_G(pick_group((double)NNZ / (double)std::max<int64_t>(M, 1)), k_csc_keys, M, stream, M, lp_rowptr.p, lp_col.p, k_in.p,
+                     p_in.p, c_cnt.p);
+            check_launch();
+        }
+        exclusive_scan(c_cnt.p, c_ptr.p, (size_t)n_lp + 1);
+        if (NNZ > 0) {
+            int bits = 1;
+            while (((int64_t)1 << bits) < n_lp + 1 && bits < 31) ++bits;
+            size_t need = sort_pairs_temp_bytes((size_t)NNZ);
+            d_sorttmp.resize(need + 16, stream);
+            // keys are (col << 32 | row) in CSR order, i.e. already ascending in row: a STABLE sort on the column bits alone
+            // gives (col, row) order in 3 radix passes instead of 7
+            KTN_HIP(sort_pairs_u64_u32(d_sorttmp.p, need, k_in.p, k_out.p, p_in.p, p_out.p, (size_t)NNZ, 32, 32 + bits, stream));
+            LAUNCH_1(k_csc_rows_perm, NNZ, stream, NNZ, k_out.p, p_out.p, c_row.p, c_perm.p);
+            check_launch();
+        }
+        stats["lp_csc_sorts"] += 1.0;
     }
-    exclusive_scan(c_cnt.p, c_ptr.p, (size_t)n_lp + 1);
-    if (NNZ > 0) {
-        int bits = 1;
-        while (((int64_t)1 << bits) < n_lp + 1 && bits < 31) ++bits;
-        size_t need = sort_pairs_temp_bytes((size_t)NNZ);
-        d_sorttmp.resize(need + 16, stream);
-        // keys are (col << 32 | row) in CSR order, i.e. already ascending in row: a STABLE sort on the column bits alone
-        // gives (col, row) order in 3 radix passes instead of 7
-        KTN_HIP(sort_pairs_u64_u32(d_sorttmp.p, need, k_in.p, k_out.p, p_in.p, p_out.p, (size_t)NNZ, 32, 32 + bits, stream));
-        LAUNCH_1(k_csc_gather, NNZ, stream, NNZ, k_out.p, p_out.p, Wval(), c_row.p, c_val.p);
-        check_launch();
-    }
+    LAUNCH_1(k_csc_vals, NNZ, stream, NNZ, c_perm.p, Wval(), c_val.p);
+    check_launch();
+    csc_epoch = lp_epoch; csc_M = M; csc_NNZ = NNZ;
     lp_dirty = false;
     blocks_built_rows = -1;
+}
+// rows [csc_M, M) were appended since the mirror was built (kernels.hpp "append-only update of the mirror")
+void Engine::csc_merge_appended() {
+    const int64_t n = n_lp, nnz_new = NNZ - csc_NNZ;
+    c_off.resize((size_t)n + 1, stream);
+    c_cnt.resize((size_t)n + 1, stream);
+    c_cnt.zero(stream);
+    LAUNCH_1(k_cscm_count, nnz_new, stream, csc_NNZ, NNZ, lp_col.p, c_cnt.p);
+    exclusive_scan(c_cnt.p, c_off.p, (size_t)n + 1);
+    c_ptr2.resize((size_t)n + 1, stream);
+    c_row2.resize((size_t)NNZ + 1, stream);
+    c_perm2.resize((size_t)NNZ + 1, stream);
+    const int gc = pick_group((double)csc_NNZ / (double)std::max<int64_t>(n, 1));
+    LAUNCH_G(gc, k_cscm_move, n + 1, stream, n, c_ptr.p, c_off.p, c_row.p, c_perm.p, c_ptr2.p, c_row2.p, c_perm2.p);
+    c_cnt.zero(stream);
+    LAUNCH_1(k_cscm_place, M - csc_M, stream, csc_M, M, lp_rowptr.p, lp_col.p, c_ptr.p, c_off.p, c_cnt.p, c_row2.p, c_perm2.p);
+    LAUNCH_1(k_cscm_order, n, stream, n, c_ptr.p, c_off.p, c_row2.p, c_perm2.p);
+    check_launch();
+    c_ptr.swap(c_ptr2); c_row.swap(c_row2); c_perm.swap(c_perm2);
 }
 
 // The matrix a solve works on: the stored LP, or its epigraph-shifted working form (kernels.hpp "epigraph reference
@@ -1410,7 +1449,7 @@ void Engine::purge_cuts() {
     purged_total += m - m_new;
     stats["purges"] += 1.0;
     M = m_new; NNZ = nnz_new;
-    lp_dirty = true; ++lp_version;
+    lp_dirty = true; ++lp_version; ++lp_epoch;
 }
 
 void Engine::compute_scaling(bool identity) {
@@ -2998,7 +3037,7 @@ int ktn_lp_truncate(ktn_handle h, int64_t nrows) {
         e->lp_lo.n = e->lp_hi.n = e->lp_y.n = (size_t)nrows;
         if (e->d_age.n > (size_t)nrows) e->d_age.n = (size_t)nrows;
         if (e->d_cutprev.n > (size_t)nrows) e->d_cutprev.n = (size_t)nrows;
-        e->lp_dirty = true; ++e->lp_version;
+        e->lp_dirty = true; ++e->lp_version; ++e->lp_epoch;
         return KTN_OK;
     })
 }

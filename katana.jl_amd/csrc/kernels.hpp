@@ -1914,13 +1914,76 @@ __global__ __launch_bounds__(kBlock) void k_csc_keys(int64_t m, const int64_t* _
         atomicAdd(reinterpret_cast<unsigned long long*>(&colcount[c]), 1ULL);
     }
 }
-__global__ __launch_bounds__(kBlock) void k_csc_gather(int64_t nnz, const uint64_t* __restrict__ keys,
-                                                       const uint32_t* __restrict__ perm, const double* __restrict__ val,
-                                                       int32_t* __restrict__ crow, double* __restrict__ cval) {
+// ---- append-only update of the mirror ------------------------------------------------------------------------------
+// Between two purges rows are only ever APPENDED (src/model.jl:74-77: cuts are added, never changed), and an appended row has
+// a larger index than every row already mirrored: column j of the new mirror is column j of the old one followed by j's
+// entries in the new rows, in row order.  So instead of sorting all non-zeros again (three radix passes over 5e5 pairs per LP
+// solve on cfg3) the old columns are shifted by the running count of new entries and the new entries dropped in behind
+// them.  The mirror keeps, per position, the CSR entry it came from (perm): values are gathered through it, which is also
+// what lets the epigraph-shifted working form refresh its values without touching the structure.
+__global__ __launch_bounds__(kBlock) void k_cscm_count(int64_t e0, int64_t nnz, const int32_t* __restrict__ col, int64_t* __restrict__ cnt) {
+    const int64_t e = e0 + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e < nnz) atomicAdd(reinterpret_cast<unsigned long long*>(&cnt[col[e]]), 1ULL);
+}
+// old column j moves to old_ptr[j] + off[j] (off = exclusive scan of the new entries per column); G lanes per column
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_cscm_move(int64_t n, const int64_t* __restrict__ old_ptr, const int64_t* __restrict__ off,
+                                                      const int32_t* __restrict__ old_row, const uint32_t* __restrict__ old_perm,
+                                                      int64_t* __restrict__ new_ptr, int32_t* __restrict__ new_row,
+                                                      uint32_t* __restrict__ new_perm) {
+    const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (j > n) return;
+    if (j == n) { if (lane == 0) new_ptr[n] = old_ptr[n] + off[n]; return; }
+    const int64_t src = old_ptr[j], len = old_ptr[j + 1] - src, dst = src + off[j];
+    for (int64_t k = lane; k < len; k += G) { new_row[dst + k] = old_row[src + k]; new_perm[dst + k] = old_perm[src + k]; }
+    if (lane == 0) new_ptr[j] = dst;
+}
+// the entries of the new rows [m0, m) behind their columns' old entries, in arrival order (cursor zeroed) ...
+__global__ __launch_bounds__(kBlock) void k_cscm_place(int64_t m0, int64_t m, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       const int64_t* __restrict__ old_ptr, const int64_t* __restrict__ off,
+                                                       int64_t* __restrict__ cursor, int32_t* __restrict__ new_row,
+                                                       uint32_t* __restrict__ new_perm) {
+    const int64_t r = m0 + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= m) return;
+    for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+        const int32_t j = col[e];
+        const int64_t k = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(&cursor[j]), 1ULL);
+        const int64_t pos = old_ptr[j + 1] + off[j] + k;
+        new_row[pos] = (int32_t)r;
+        new_perm[pos] = (uint32_t)e;
+    }
+}
+// ... and put into row order column by column (a column gets 0.3 new entries per sweep on average: an insertion sort of a
+// handful), so that every column sum keeps its fixed order whatever the arrival order was
+__global__ __launch_bounds__(kBlock) void k_cscm_order(int64_t n, const int64_t* __restrict__ old_ptr, const int64_t* __restrict__ off,
+                                                       int32_t* __restrict__ new_row, uint32_t* __restrict__ new_perm) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    const int64_t cnt = off[j + 1] - off[j];
+    if (cnt < 2) return;
+    const int64_t b = old_ptr[j + 1] + off[j];
+    for (int64_t a = 1; a < cnt; ++a) {
+        const int32_t rr = new_row[b + a];
+        const uint32_t pp = new_perm[b + a];
+        int64_t q = a - 1;
+        while (q >= 0 && (new_row[b + q] > rr || (new_row[b + q] == rr && new_perm[b + q] > pp))) {
+            new_row[b + q + 1] = new_row[b + q]; new_perm[b + q + 1] = new_perm[b + q]; --q;
+        }
+        new_row[b + q + 1] = rr; new_perm[b + q + 1] = pp;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_csc_vals(int64_t nnz, const uint32_t* __restrict__ perm, const double* __restrict__ val,
+                                                     double* __restrict__ cval) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p < nnz) cval[p] = val[perm[p]];
+}
+__global__ __launch_bounds__(kBlock) void k_csc_rows_perm(int64_t nnz, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ perm,
+                                                          int32_t* __restrict__ crow, uint32_t* __restrict__ cperm) {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= nnz) return;
     crow[p] = (int32_t)(keys[p] & 0xffffffffULL);
-    cval[p] = val[perm[p]];
+    cperm[p] = perm[p];
 }
 
 // recession-LP box of the epigraph variable: 1 + max_r sum_{j != aux} |a_rj| / |a_r,aux|

@@ -231,3 +231,28 @@ def test_tiled_spmv_steps_match_the_csr_steps():
     assert m.optimize() == "Optimal" and m.stat("lp_tiled_builds") >= 1
     assert abs(m.getobjval() - inst.opt_obj) <= planted_obj_bound(inst)
     assert max_nl_violation(inst, m.getsolution()) <= 1e-6 * (1 + 1e-6)
+
+
+def test_append_only_mirror_update_gives_the_sorted_mirror_bit_for_bit(monkeypatch):
+    """the column mirror of the growing LP: between purges it is extended by a merge of the appended rows (kernels.hpp
+    "append-only update of the mirror") instead of a sort of all non-zeros.  Both give every column its entries in row order, so
+    the two solves run the same arithmetic: identical objective, PDHG iteration count and x -- with and without purging (which
+    forces a fresh sort), and with a nonlinear objective (dense epigraph cuts whose working values change every solve)."""
+    import katana_jl_amd as ktn
+    from helpers import hip_load_instance
+    for kw, solver in ((dict(n=3000, m_nl=300, k=16, family="explog", seed=4), {}),
+                       (dict(n=3000, m_nl=300, k=16, family="explog", seed=4), dict(purge_min_rows=50)),
+                       (dict(n=2500, m_nl=200, k=16, family="quad", seed=2, objective="quad"), {})):
+        inst = ktn.instances.make_instance(**kw)
+        res = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("KTN_NO_CSC_MERGE", "1")
+            else:
+                monkeypatch.delenv("KTN_NO_CSC_MERGE", raising=False)
+            m = hip_load_instance(ktn, inst, **solver)
+            assert m.optimize() == "Optimal"
+            res.append((m.getobjval(), m.stat("pdhg_iters"), m.numiters(), m.getsolution(), m.stat("lp_csc_merges"), m.stat("lp_csc_sorts")))
+        a, b = res
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and np.array_equal(a[3], b[3])
+        assert a[4] >= a[2] - 3 and b[4] == 0 and b[5] >= b[2]           # merges in the default build, sorts only when asked
