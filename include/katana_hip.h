@@ -322,6 +322,16 @@ int ktn_lp_enable_global_lists(ktn_handle h, int64_t nl_total);
 int ktn_last_sweep_slots(ktn_handle h, int64_t* slots, int64_t cap, int64_t* count);
 int ktn_lp_append_rows_nl(ktn_handle h, int64_t nrows, const int64_t* rowptr, const int32_t* col, const double* val,
                           const double* lo, const double* hi, const int64_t* nl_id);
+/* The same exchange without leaving device memory (the north star's "RCCL all-gather of generated cuts over xGMI"): the rows
+ * [first_row, M) -- the cuts a sweep just appended -- are written as ONE f64 block
+ *     [rowptr[1:] rebased | col | val | lo | hi | global NL-row id = id_offset + local NL slot]      (4 nrows + 2 nnz doubles)
+ * into a DEVICE buffer of the caller (dev_out == NULL: size query only), all-gathered by the caller (RCCL), and every rank's
+ * block is appended from the device receive buffer by ktn_lp_append_packed_dev, with the bookkeeping of
+ * ktn_lp_append_rows_nl.  Both calls return with the engine's stream idle; the caller synchronises its own stream between
+ * the all-gather and the appends. */
+int ktn_lp_pack_rows_dev(ktn_handle h, int64_t first_row, int64_t id_offset, double* dev_out, int64_t cap,
+                         int64_t* nrows, int64_t* nnz);
+int ktn_lp_append_packed_dev(ktn_handle h, int64_t nrows, int64_t nnz, const double* dev_in);
 /* cut-pool purge after an LP solve (what ktn_ecp_step does between the LP and the sweep); deterministic, so ranks that
  * hold identical LPs stay identical */
 int ktn_lp_purge(ktn_handle h, int64_t* rows_removed);

@@ -93,6 +93,8 @@ PROTOTYPES = {
     "ktn_lp_nnz_from": (c_i64, [C.c_void_p, c_i64]),
     "ktn_lp_get_rows_from": (c_i32, [C.c_void_p, c_i64, P(c_i64), P(c_i32), P(c_f64), P(c_f64), P(c_f64)]),
     "ktn_lp_truncate": (c_i32, [C.c_void_p, c_i64]),
+    "ktn_lp_pack_rows_dev": (c_i32, [C.c_void_p, c_i64, c_i64, C.c_void_p, c_i64, P(c_i64), P(c_i64)]),
+    "ktn_lp_append_packed_dev": (c_i32, [C.c_void_p, c_i64, c_i64, C.c_void_p]),
     "ktn_lp_purge": (c_i32, [C.c_void_p, P(c_i64)]),
     "ktn_lp_enable_global_lists": (c_i32, [C.c_void_p, c_i64]),
     "ktn_last_sweep_slots": (c_i32, [C.c_void_p, P(c_i64), c_i64, P(c_i64)]),

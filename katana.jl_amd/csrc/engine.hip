@@ -241,6 +241,10 @@ struct Engine {
         LAUNCH_1(k_append_link, nrows, stream, nrows, M, d_nlid.p, nl_total, d_glast.p, d_cutprev.p, lp_y.p, (int)prm.lp_dual_inherit);
         check_launch();
     }
+    void append_link_dev(int64_t nrows) {                              // the same with the ids already in d_nlid (device-resident exchange)
+        LAUNCH_1(k_append_link, nrows, stream, nrows, M, d_nlid.p, nl_total, d_glast.p, d_cutprev.p, lp_y.p, (int)prm.lp_dual_inherit);
+        check_launch();
+    }
     int64_t* list_heads() { return glists ? d_glast.p : d_lastcut.p; }
     int64_t list_count() const { return glists ? nl_total : m_nl; }
     bool lists_ok() const { return !sharded_rows || glists; }
@@ -3200,6 +3204,65 @@ int ktn_lp_append_rows_nl(ktn_handle h, int64_t nrows, const int64_t* rowptr, co
         }
         e->sync();
         e->M += nrows; e->NNZ += nz; e->numcuts += nrows;
+        e->sharded_rows = true;
+        e->lp_dirty = true; ++e->lp_version;
+        return KTN_OK;
+    })
+}
+
+// ---- device-resident cut exchange (replicated LP over several GPUs): the packed block of kernels.hpp "cut blocks for the
+// exchange" is written into / read from DEVICE buffers of the caller (torch tensors handed to RCCL's all-gather)
+int ktn_lp_pack_rows_dev(ktn_handle h, int64_t first_row, int64_t id_offset, double* dev_out, int64_t cap, int64_t* nrows, int64_t* nnz) {
+    KTN_TRY(h, {
+        using namespace ktn;
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && first_row >= 0 && first_row <= e->M && nrows && nnz, "pack_rows_dev: bad arguments");
+        const int64_t nr = e->M - first_row;
+        int64_t base = e->NNZ;
+        if (nr > 0) {
+            KTN_HIP(hipMemcpyAsync(&base, e->lp_rowptr.p + first_row, 8, hipMemcpyDeviceToHost, e->stream));
+            e->sync();
+        }
+        const int64_t nz = e->NNZ - base;
+        *nrows = nr; *nnz = nz;
+        if (!dev_out) return KTN_OK;                                   // size query
+        KTN_REQUIRE(cap >= 4 * nr + 2 * nz, "pack_rows_dev: buffer too small");
+        const bool ids = e->last_sweep_cuts == nr && nr > 0;          // the rows of the last sweep carry their NL slot
+        LAUNCH_1(k_pack_rows, std::max(nr, nz), e->stream, nr, nz, e->lp_rowptr.p + first_row, e->lp_col.p + base, e->lp_val.p + base,
+                 e->lp_lo.p + first_row, e->lp_hi.p + first_row, ids ? (const int32_t*)e->d_violslots.p : (const int32_t*)nullptr,
+                 id_offset, dev_out);
+        e->check_launch();
+        e->sync();                                                     // the caller's stream may read the buffer now
+        return KTN_OK;
+    })
+}
+int ktn_lp_append_packed_dev(ktn_handle h, int64_t nrows, int64_t nnz, const double* dev_in) {
+    KTN_TRY(h, {
+        using namespace ktn;
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && nrows >= 0 && nnz >= 0 && (dev_in || nrows == 0), "append_packed_dev: bad arguments");
+        if (nrows == 0) return KTN_OK;
+        hipStream_t s = e->stream;
+        e->lp_rowptr.resize((size_t)(e->M + nrows + 1), s);
+        e->lp_lo.resize((size_t)(e->M + nrows), s); e->lp_hi.resize((size_t)(e->M + nrows), s);
+        e->lp_y.resize((size_t)(e->M + nrows), s);
+        e->lp_col.resize((size_t)(e->NNZ + nnz), s); e->lp_val.resize((size_t)(e->NNZ + nnz), s);
+        e->d_age.resize((size_t)(e->M + nrows), s); e->d_cutprev.resize((size_t)(e->M + nrows), s);
+        e->d_nlid.resize((size_t)nrows, s);
+        KTN_HIP(hipMemsetAsync(e->lp_y.p + e->M, 0, (size_t)nrows * 8, s));
+        KTN_HIP(hipMemsetAsync(e->d_age.p + e->M, 0, (size_t)nrows * sizeof(int32_t), s));
+        KTN_HIP(hipMemsetAsync(e->d_cutprev.p + e->M, 0xFF, (size_t)nrows * sizeof(int64_t), s));
+        KTN_HIP(hipMemsetAsync(e->d_anynf.p + 1, 0, sizeof(int32_t), s));
+        LAUNCH_1(k_unpack_rows, std::max(nrows, nnz), s, nrows, nnz, dev_in, e->NNZ, e->n_lp, e->lp_rowptr.p + e->M + 1, e->lp_col.p + e->NNZ,
+                 e->lp_val.p + e->NNZ, e->lp_lo.p + e->M, e->lp_hi.p + e->M, e->d_nlid.p, e->d_anynf.p + 1);
+        e->check_launch();
+        if (e->glists) e->append_link_dev(nrows);
+        int32_t bad = 0;
+        KTN_HIP(hipMemcpyAsync(&bad, e->d_anynf.p + 1, 4, hipMemcpyDeviceToHost, s));
+        e->sync();
+        KTN_REQUIRE(bad == 0, "append_packed_dev: malformed block (row pointers not monotone or column out of range)");
+        e->M += nrows; e->NNZ += nnz; e->numcuts += nrows;
+        e->max_row_len = (int64_t)1 << 62;                             // (row lengths of other ranks' cuts are not known on the host)
         e->sharded_rows = true;
         e->lp_dirty = true; ++e->lp_version;
         return KTN_OK;

@@ -1986,6 +1986,50 @@ __global__ __launch_bounds__(kBlock) void k_csc_rows_perm(int64_t nnz, const uin
     cperm[p] = perm[p];
 }
 
+// ---- cut blocks for the exchange between GPUs, packed and unpacked on the device ------------------------------------
+// One f64 block per rank: [rowptr[1:] (rebased) | col | val | lo | hi | global NL-row id], integers exact in f64 -- the
+// layout katana_jl_amd/distributed.py::pack_block uses on the host path.  The block never leaves device memory: the engine
+// writes it into the caller's send buffer, RCCL all-gathers it, the engine appends every rank's block from the receive
+// buffers (ktn_lp_pack_rows_dev / ktn_lp_append_packed_dev).
+__global__ __launch_bounds__(kBlock) void k_pack_rows(int64_t nr, int64_t nz, const int64_t* __restrict__ rowptr /* at first_row */,
+                                                      const int32_t* __restrict__ col, const double* __restrict__ val /* at base */,
+                                                      const double* __restrict__ lo, const double* __restrict__ hi,
+                                                      const int32_t* __restrict__ slots, int64_t id_offset, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t base = rowptr[0];
+    if (i < nr) {
+        out[i] = (double)(rowptr[i + 1] - base);
+        out[nr + 2 * nz + i] = lo[i];
+        out[2 * nr + 2 * nz + i] = hi[i];
+        out[3 * nr + 2 * nz + i] = slots ? (double)(id_offset + slots[i]) : -1.0;
+    }
+    if (i < nz) {
+        out[nr + i] = (double)col[i];
+        out[nr + nz + i] = val[i];
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_unpack_rows(int64_t nr, int64_t nz, const double* __restrict__ in, int64_t nnz0,
+                                                        int64_t n_lp, int64_t* __restrict__ rowptr /* at M + 1 */,
+                                                        int32_t* __restrict__ col, double* __restrict__ val /* at nnz0 */,
+                                                        double* __restrict__ lo, double* __restrict__ hi /* at M */,
+                                                        int64_t* __restrict__ nl_id, int32_t* __restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < nr) {
+        const int64_t end = (int64_t)in[i], beg = i ? (int64_t)in[i - 1] : 0;
+        if (end < beg || end > nz) atomicOr(bad, 1);
+        rowptr[i] = nnz0 + end;
+        lo[i] = in[nr + 2 * nz + i];
+        hi[i] = in[2 * nr + 2 * nz + i];
+        nl_id[i] = (int64_t)in[3 * nr + 2 * nz + i];
+    }
+    if (i < nz) {
+        const int64_t c = (int64_t)in[nr + i];
+        if (c < 0 || c >= n_lp) atomicOr(bad, 2);
+        col[i] = (int32_t)c;
+        val[i] = in[nr + nz + i];
+    }
+}
+
 // recession-LP box of the epigraph variable: 1 + max_r sum_{j != aux} |a_rj| / |a_r,aux|
 __global__ __launch_bounds__(kBlock) void k_aux_box(int64_t m, const int64_t* __restrict__ rowptr,
                                                     const int32_t* __restrict__ col, const double* __restrict__ val,

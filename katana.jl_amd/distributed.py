@@ -101,6 +101,47 @@ def _gather_blocks(dist, device, world, all_counts, with_ids, rowptr, col, val, 
     return [unpack_block(recv[r].cpu().numpy(), *all_counts[r], with_ids=with_ids) for r in range(world)]
 
 
+def exchange_cuts_dev(dist, model, first_row, id_offset, scalars):
+    """The same exchange with the cut blocks resident in device memory from the sweep that generated them to the LP that
+    receives them (the north star's "RCCL all-gather of generated cuts over xGMI"): the engine packs the rows [first_row, M)
+    into a torch CUDA tensor (ktn_lp_pack_rows_dev), `dist.all_gather` moves the padded blocks between the GPUs -- RCCL when
+    the process group is "nccl"; a gloo group (tests: ranks sharing one GPU) cannot gather CUDA tensors and stages that one
+    call through the host -- and every rank's block is appended from the receive buffer (ktn_lp_append_packed_dev).  Only
+    the four sizes / flags per rank cross to the host.  Returns (rows appended, max over ranks of scalars[0], of scalars[1]);
+    the model's own rows >= first_row are replaced by the gathered ones, in rank order."""
+    import torch
+    world = dist.get_world_size()
+    nccl = dist.get_backend() == "nccl"
+    nr, nz = model.lp_pack_rows_dev(first_row, id_offset)
+    counts = torch.tensor([float(nr), float(nz), float(scalars[0]), float(scalars[1])], dtype=torch.float64, device="cuda" if nccl else "cpu")
+    all_counts = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts)                       # collective 1: sizes (+ the two scalars)
+    all_counts = [c.cpu() for c in all_counts]
+    max_a, max_b = max(float(c[2]) for c in all_counts), max(float(c[3]) for c in all_counts)
+    sizes = [(int(c[0]), int(c[1])) for c in all_counts]
+    width = max(4 * r + 2 * z for r, z in sizes)
+    if width == 0 or max_b >= 2.0:                            # nothing to move, or some rank's LP failed: the caller leaves the loop
+        model.lp_truncate(first_row)
+        return 0, max_a, max_b
+    send = torch.zeros(width, dtype=torch.float64, device="cuda")
+    model.lp_pack_rows_dev(first_row, id_offset, send.data_ptr(), width)
+    model.lp_truncate(first_row)
+    recv = [torch.empty(width, dtype=torch.float64, device="cuda") for _ in range(world)]
+    if nccl:
+        dist.all_gather(recv, send)                           # collective 2: padded cut blocks, device to device
+    else:
+        host = [torch.empty(width, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(host, send.cpu())
+        for r in range(world):
+            recv[r].copy_(host[r])
+    torch.cuda.current_stream().synchronize()                 # the engine reads the buffers on its own stream
+    total = 0
+    for r, (rows, nnz) in enumerate(sizes):                   # rank order => identical LP everywhere
+        model.lp_append_packed_dev(rows, nnz, recv[r].data_ptr())
+        total += rows
+    return total, max_a, max_b
+
+
 class ShardedKatanaModel:
     """KatanaNonlinearModel over `world` GPUs: same getters, same stepping interface."""
 
@@ -128,6 +169,8 @@ class ShardedKatanaModel:
         prm = self.m.params
         self.tol = dict(scale=prm.lp_tol_scale, floor=prm.lp_tol_floor, cap=prm.lp_tol_cap, gfloor=prm.lp_gap_floor,
                         gcap=prm.lp_gap_cap)
+        # "cuda": the cut blocks stay in device memory end to end (exchange_cuts_dev; the default over RCCL); "cpu": blocks are
+        # downloaded, gathered as host tensors and uploaded again (exchange_cuts; gloo groups, world 1)
         if exchange_device is None:
             exchange_device = "cpu" if (dist is None or dist.get_backend() == "gloo") else "cuda"
         self.exchange_device = exchange_device
@@ -158,13 +201,16 @@ class ShardedKatanaModel:
         lp_status, _ = self.m.lp_solve(tol_p, tol_g)
         lp_ok = lp_status == "Optimal"
         m0 = self.m.lp_num_rows()
+        device_resident = self.exchange_device == "cuda" and self.dist is not None and self.world > 1
+        block = None
         if lp_ok:
             self.purged_rows += self.m.lp_purge()                 # identical LPs => identical purge on every rank
             m0 = self.m.lp_num_rows()
             nv_local, mv_local = self.m.sweep_lp_point(f_tol)
             err_local = self.m.status() == "Error"
-            block = tuple(self.m.lp_rows_from(m0)) + (self.shard_lo + self.m.last_sweep_slots(),)
-            self.m.lp_truncate(m0)
+            if not device_resident:
+                block = tuple(self.m.lp_rows_from(m0)) + (self.shard_lo + self.m.last_sweep_slots(),)
+                self.m.lp_truncate(m0)
         else:                                                     # still take part in this iteration's exchange
             mv_local, err_local = 0.0, False
             block = (np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0), np.zeros(0),
@@ -172,14 +218,20 @@ class ShardedKatanaModel:
         # Two collectives per iteration.  The status flags ride with the size exchange: every rank must leave the loop in
         # the same iteration (one that returned early would leave the others waiting in the next collective).
         flag = (2.0 if not lp_ok else 0.0) + (1.0 if err_local else 0.0)
-        blocks, maxviol, flags = exchange_cuts(self.dist, block, self.exchange_device, scalars=(mv_local, flag))
-        if flags >= 2.0:
-            self._status = lp_status if not lp_ok else "Error"
-            return True
-        nviol = 0
-        for rp, col, val, lo, hi, ids in blocks:                 # rank order => identical LP everywhere
-            self.m.lp_append_rows(rp, col, val, lo, hi, ids)
-            nviol += len(lo)
+        if device_resident:
+            nviol, maxviol, flags = exchange_cuts_dev(self.dist, self.m, m0, self.shard_lo, (mv_local, flag))
+            if flags >= 2.0:
+                self._status = lp_status if not lp_ok else "Error"
+                return True
+        else:
+            blocks, maxviol, flags = exchange_cuts(self.dist, block, self.exchange_device, scalars=(mv_local, flag))
+            if flags >= 2.0:
+                self._status = lp_status if not lp_ok else "Error"
+                return True
+            nviol = 0
+            for rp, col, val, lo, hi, ids in blocks:             # rank order => identical LP everywhere
+                self.m.lp_append_rows(rp, col, val, lo, hi, ids)
+                nviol += len(lo)
         self.exchanged_rows += nviol
         if flags >= 1.0:
             self._status = "Error"

@@ -193,6 +193,17 @@ class KatanaNonlinearModel:
                                                         _p(val), _p(lo), _p(hi)))
         return rowptr, col[:nz], val[:nz], lo[:nr], hi[:nr]
 
+    def lp_pack_rows_dev(self, first_row, id_offset, dev_ptr=0, cap=0):
+        """(nrows, nnz) of the rows [first_row, M); with a device pointer the packed f64 block of those rows is written there
+        (ktn_lp_pack_rows_dev: the device-resident half of the cut exchange)"""
+        nr, nz = C.c_int64(0), C.c_int64(0)
+        L.check(self._h, self._lib.ktn_lp_pack_rows_dev(self._h, first_row, id_offset, C.c_void_p(dev_ptr or None), cap,
+                                                        C.byref(nr), C.byref(nz)))
+        return int(nr.value), int(nz.value)
+
+    def lp_append_packed_dev(self, nrows, nnz, dev_ptr):
+        L.check(self._h, self._lib.ktn_lp_append_packed_dev(self._h, nrows, nnz, C.c_void_p(dev_ptr or None)))
+
     def lp_truncate(self, nrows):
         L.check(self._h, self._lib.ktn_lp_truncate(self._h, nrows))
 

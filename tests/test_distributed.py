@@ -121,14 +121,15 @@ def test_pack_unpack_roundtrip_with_empty_and_ragged_blocks():
         assert len(got) == 6 and np.array_equal(got[5], ids) and np.array_equal(got[1], col)
 
 
-def _worker_gpu(rank, world, port, out, inst_kw=None, solver_kw=None):
+def _worker_gpu(rank, world, port, out, inst_kw=None, solver_kw=None, exchange_device=None):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     import katana_jl_amd as ktn
     from katana_jl_amd.distributed import ShardedKatanaModel
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     inst = ktn.instances.make_instance(**(inst_kw or dict(n=4000, m_nl=400, k=16, family="explog", seed=21)))
-    m = ShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0, **(solver_kw or dict(purge_age=0))), inst, rank, world, dist)
+    m = ShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0, **(solver_kw or dict(purge_age=0))), inst, rank, world, dist,
+                           exchange_device=exchange_device)
     st = m.optimize()
     out[rank] = (st, m.getobjval(), m.numiters(), m.numcuts(), m.getsolution(), m.purged_rows, m.m.lp_num_rows())
     dist.destroy_process_group()
@@ -151,6 +152,31 @@ def test_two_rank_sharded_solve_matches_single_gpu():
     assert o0 == single.getobjval() and it0 == single.numiters() and c0 == single.numcuts()
     assert abs(o0 - inst.opt_obj) <= planted_obj_bound(inst)
     assert max_nl_violation(inst, x0) <= 1e-6 * (1 + 1e-6)
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_solve_with_the_device_resident_cut_exchange():
+    """the cut blocks never leave device memory: packed by the engine into a torch CUDA tensor (ktn_lp_pack_rows_dev), gathered,
+    appended from the receive buffers (ktn_lp_append_packed_dev).  Two ranks share cuda:0 here, so the gather itself runs over
+    gloo (which stages CUDA tensors through the host); over RCCL the same tensors go GPU to GPU.  The trajectory is the one of
+    the host-staged exchange and of the single-GPU solve, bit for bit -- with purging and deepest-cut selection on as well."""
+    import katana_jl_amd as ktn
+    from helpers import hip_load_instance, max_nl_violation, planted_obj_bound
+    world = 2
+    for solver_kw in (dict(purge_age=0), dict(purge_age=2, purge_min_rows=50, cut_cap_factor=0.02, cut_cap_min=20)):
+        out_dev, out_host = mp.Manager().dict(), mp.Manager().dict()
+        mp.spawn(_worker_gpu, args=(world, _free_port(), out_dev, None, solver_kw, "cuda"), nprocs=world, join=True)
+        mp.spawn(_worker_gpu, args=(world, _free_port(), out_host, None, solver_kw, "cpu"), nprocs=world, join=True)
+        inst = ktn.instances.make_instance(n=4000, m_nl=400, k=16, family="explog", seed=21)
+        for r in range(world):
+            assert out_dev[r][0] == "Optimal"
+            assert out_dev[r][1] == out_host[r][1] and out_dev[r][2] == out_host[r][2] and out_dev[r][3] == out_host[r][3]
+            assert np.array_equal(out_dev[r][4], out_host[r][4]) and out_dev[r][6] == out_host[r][6]
+        assert out_dev[0][1] == out_dev[1][1] and np.array_equal(out_dev[0][4], out_dev[1][4])
+        assert abs(out_dev[0][1] - inst.opt_obj) <= planted_obj_bound(inst)
+        assert max_nl_violation(inst, out_dev[0][4]) <= 1e-6 * (1 + 1e-6)
+    single = hip_load_instance(ktn, inst, purge_age=0)
+    assert single.optimize() == "Optimal"
 
 
 @pytest.mark.gpu
