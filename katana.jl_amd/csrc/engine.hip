@@ -1339,7 +1339,8 @@ void Engine::csc_merge_appended() {
     const int gc = pick_group((double)csc_NNZ / (double)std::max<int64_t>(n, 1));
     LAUNCH_G(gc, k_cscm_move, n + 1, stream, n, c_ptr.p, c_off.p, c_row.p, c_perm.p, c_ptr2.p, c_row2.p, c_perm2.p);
     c_cnt.zero(stream);
-    LAUNCH_1(k_cscm_place, M - csc_M, stream, csc_M, M, lp_rowptr.p, lp_col.p, c_ptr.p, c_off.p, c_cnt.p, c_row2.p, c_perm2.p);
+    LAUNCH_G(pick_group((double)nnz_new / (double)std::max<int64_t>(M - csc_M, 1)), k_cscm_place, M - csc_M, stream, csc_M, M, lp_rowptr.p, lp_col.p, c_ptr.p,
+             c_off.p, c_cnt.p, c_row2.p, c_perm2.p);
     LAUNCH_1(k_cscm_order, n, stream, n, c_ptr.p, c_off.p, c_row2.p, c_perm2.p);
     check_launch();
     c_ptr.swap(c_ptr2); c_row.swap(c_row2); c_perm.swap(c_perm2);

@@ -1940,13 +1940,15 @@ __global__ __launch_bounds__(kBlock) void k_cscm_move(int64_t n, const int64_t* 
     if (lane == 0) new_ptr[j] = dst;
 }
 // the entries of the new rows [m0, m) behind their columns' old entries, in arrival order (cursor zeroed) ...
+template <int G>
 __global__ __launch_bounds__(kBlock) void k_cscm_place(int64_t m0, int64_t m, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                        const int64_t* __restrict__ old_ptr, const int64_t* __restrict__ off,
                                                        int64_t* __restrict__ cursor, int32_t* __restrict__ new_row,
                                                        uint32_t* __restrict__ new_perm) {
-    const int64_t r = m0 + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t r = m0 + ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
     if (r >= m) return;
-    for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+    for (int64_t e = rowptr[r] + lane; e < rowptr[r + 1]; e += G) {        // (a thread per row walked its 32 atomics one after the other: 57 us)
         const int32_t j = col[e];
         const int64_t k = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(&cursor[j]), 1ULL);
         const int64_t pos = old_ptr[j + 1] + off[j] + k;

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round profile: rocprofv3 kernel stats of the bench command, PMC FETCH_SIZE / WRITE_SIZE passes (separate passes: gpurun
 # refuses --pmc together with trace domains other than --kernel-trace), the same for the HBM-regime SpMV microbenchmark and
-# the HBM-resident sweep.  Writes summaries under gpurun_out/prof_r02/ (copy what is to be judged into profiles/).
+# the HBM-resident sweep.  Writes summaries under gpurun_out/prof_r03/ (copy what is to be judged into profiles/).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof_r02
+OUT=$R/gpurun_out/prof_r03
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run_stats() {  # name, args...
@@ -27,6 +27,7 @@ run_pmc spmv_hbm FETCH_SIZE $R/tools/spmv_bench.py 1000000 8
 run_pmc spmv_hbm WRITE_SIZE $R/tools/spmv_bench.py 1000000 8
 run_stats sweep_hbm $R/tools/sweep_bench.py cfg3_hbm 20
 run_pmc sweep_hbm FETCH_SIZE $R/tools/sweep_bench.py cfg3_hbm 8
+run_stats sweep_short $R/tools/sweep_viol.py cfg4 8          # the row sweep on 1e6 short rows (bench.py sweep_roofline_short_rows)
 cd $R
 python3 bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
 python3 tools/spmv_bench.py 1000000 40 2>/dev/null | tail -1 > $OUT/spmv_hbm.json
