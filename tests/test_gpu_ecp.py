@@ -434,3 +434,51 @@ def test_objective_certificate_equals_the_distance_to_the_planted_optimum_and_dr
             assert m.numiters() == plain.numiters()                        # refinement passes are not ECP iterations
         else:
             assert m.getobjval() == plain.getobjval()
+
+
+def test_epigraph_reference_shift_is_an_exact_change_of_variables():
+    """kernels.hpp "epigraph reference shift": the LP of a nonlinear-objective problem solved relative to the newest epigraph
+    cut (t = s + a_ref'x + b_ref) is the same LP -- same objective as in the reference's own form (epi_shift = 0), same
+    aux variable t = f(x) at the optimum (src/model.jl:340-341), same cuts exported in the reference's form."""
+    inst = ktn.instances.make_instance(n=3000, m_nl=300, k=16, family="quad", seed=1, objective="quad")
+    res = []
+    for shift in (1, 0):
+        m = hip_load_instance(ktn, inst, epi_shift=shift, purge_age=0)
+        assert m.optimize() == "Optimal"
+        x = m.getsolution()
+        f = float(np.sum(inst.obj_p0 * (x[:inst.n] - inst.obj_p1) ** 2))
+        assert abs(x[inst.n] - m.getobjval()) <= 1e-9 * max(1.0, abs(f))            # the epigraph variable IS the LP objective
+        assert -1e-7 * abs(f) <= f - x[inst.n] <= 1e-6 * (1 + 1e-6)     # f(x) - t <= f_tol (the stop rule on the epigraph row); t above f only by the LP's gap tolerance
+        assert (m.stat("lp_epi_shifts") > 0) == bool(shift)
+        assert_planted_objective(m.getobjval(), inst)
+        # every exported epigraph cut is a valid under-estimator in the reference's form: grad'x - t <= -b at the planted point
+        rp, col, val, lo, hi = m.lp_rows()
+        xt = np.concatenate([inst.xhat, [inst.opt_obj]])
+        for r in range(inst.m_lin, len(lo)):
+            c, v = col[rp[r]:rp[r + 1]], val[rp[r]:rp[r + 1]]
+            if len(c) and c[-1] == inst.n:
+                assert v[-1] == -1.0 and v @ xt[c] <= hi[r] + 1e-7 * max(1.0, abs(hi[r]))
+        res.append(m.getobjval())
+    assert abs(res[0] - res[1]) <= 2e-6 * max(1.0, abs(res[1]))
+
+
+def test_concave_objective_maximised_through_the_epigraph_shift():
+    """Max sense with a nonlinear objective (src/model.jl:144: epigraph row f(x) - t >= 0): Max -sum (x_i - 1)^2 over the unit
+    ball in 40 dimensions -- beyond the exact small-LP kernel, so the first-order LP runs in the shifted form with the
+    reference cut reading s <= 0 -- against the closed form -(sqrt(n) - 1)^2 at x = 1/sqrt(n) and against the mirrored Min."""
+    n = 40
+    out = {}
+    for sense in ("Max", "Min"):
+        M = ktn.Model(solver=ktn.KatanaSolver(log_level=0))
+        xs = M.variables(n, -2.0, 2.0)
+        sq = sum(((x - 1.0) ** 2 for x in xs[1:]), (xs[0] - 1.0) ** 2)
+        M.objective(sense, -sq if sense == "Max" else sq)
+        M.constraint((sum((x ** 2 for x in xs[1:]), xs[0] ** 2), -np.inf, 1.0))
+        assert M.solve() == "Optimal"
+        out[sense] = (M.getobjectivevalue(), M.getvalue(), M.internal_model.stat("lp_epi_shifts"), M.internal_model.stat("dense_lp_solves"))
+    want = (np.sqrt(n) - 1.0) ** 2
+    for sense, sign in (("Max", -1.0), ("Min", 1.0)):
+        obj, x, shifts, dense = out[sense]
+        assert shifts > 0 and dense == 0
+        assert abs(obj - sign * want) <= 1e-6 * max(1.0, want), (sense, obj, sign * want)     # the reference's tolerance
+        assert np.max(np.abs(x - 1.0 / np.sqrt(n))) <= 1e-3
