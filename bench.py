@@ -426,8 +426,20 @@ def main():
             tt, nl, by = dd[pfx + "_time_s"], max(dd[pfx + "_launches"], 1), dd[pfx + "_bytes"]
             spmv_roofline["kernels"][name] = {"avg_step_us": 1e6 * tt / nl, "algorithmic_bytes_per_step": by / nl,
                                               "achieved": by / tt / 1e9, "frac": by / tt / 1e9 / HBM_PEAK_GBS}
+        # the same two fractions from the committed rocprofv3 summary of tools/spmv_bench.py (k_spmv_tiled + its epilogue per step)
+        ns_t = rocprof_avg_ns(PROFILE_ROUND + "_spmv_hbm_kernel_stats.csv", "k_spmv_tiled")
+        for name, epi in (("x-step (A'y): k_spmv_tiled + k_x_epilogue", "k_x_epilogue("), ("y-step (A x): k_spmv_tiled + k_y_epilogue", "k_y_epilogue(")):
+            rec = spmv_roofline["kernels"][name]
+            rec["achieved_inprocess"], rec["frac_inprocess"] = rec["achieved"], rec["frac"]
+            ns_e = rocprof_avg_ns(PROFILE_ROUND + "_spmv_hbm_kernel_stats.csv", epi)
+            if ns_t and ns_e and spmv_roofline["tiled"]:
+                rec["avg_step_us_rocprof"] = (ns_t + ns_e) / 1e3
+                rec["achieved"] = rec["algorithmic_bytes_per_step"] / ((ns_t + ns_e) * 1e-9) / 1e9
+                rec["frac"] = rec["achieved"] / HBM_PEAK_GBS
         worst = min(spmv_roofline["kernels"].values(), key=lambda r: r["frac"])
         spmv_roofline["achieved"], spmv_roofline["frac"] = worst["achieved"], worst["frac"]
+        spmv_roofline["frac_inprocess"] = min(r["frac_inprocess"] for r in spmv_roofline["kernels"].values())
+        spmv_roofline["frac_source"] = "profiles/%s_spmv_hbm_kernel_stats.csv where present (k_spmv_tiled + epilogue), else in-process hipEvents" % PROFILE_ROUND
         tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_traffic.json")
         if os.path.exists(tpath):
             t = json.load(open(tpath)).get("k_spmv_tiled")
