@@ -401,7 +401,7 @@ struct Engine {
         }
         KTN_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         partials.resize((size_t)kRedBlocks * kChkQ * 2, stream);
-        chkout.resize(kChkQ * 2 + 8, stream);
+        chkout.resize(kChkQ * 2 + 16, stream);
         if (std::getenv("KTN_NO_PINNED_CHECK") == nullptr &&
             hipHostMalloc((void**)&h_chk, sizeof(double) * (2 * kChkQ + 16), hipHostMallocMapped) == hipSuccess) {
             if (hipHostGetDevicePointer((void**)&h_chk_dev, h_chk, 0) != hipSuccess) { (void)hipHostFree(h_chk); h_chk = nullptr; h_chk_dev = nullptr; }
@@ -2142,7 +2142,23 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         hipLaunchKernelGGL(k_dot_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, lp_c.p, lp_c.p, partials.p);
         hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, slots + 6);
     }
-    double hs[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    // Initial primal weight of a solve that has none to inherit: ||c^|| / ||b^|| with each norm taken as sqrt(count) x geometric
+    // mean of the magnitudes (KTN_OMEGA_ROBUST=0: the plain 2-norms).  A few columns whose only entries are ~1e-6 get column
+    // factors of 1e5-1e6 and with them c^_j ~ 1e6: three such columns among 1e5 make ||c^||_2 a thousand times the typical
+    // magnitude -- cfg3's first LP started at a weight of 2 686, settled at 2.7 six restarts later and took 744 iterations; with
+    // this statistic it starts at 3.2 and takes 220.  64 / 48 / 16 seeds: cfg3 -5.5 %, cfg2 -10 %, cfg4 +4 % (-3 % iterations).
+    static const int omega_robust = std::getenv("KTN_OMEGA_ROBUST") ? std::atoi(std::getenv("KTN_OMEGA_ROBUST")) : 1;
+    const bool robust = omega_robust && mode == 0 && !have_omega && !row_sharded() && m > 0;
+    if (robust) {                                       // log-magnitude statistics of c^ and of the finite row bounds: slots 8..11
+        auto logstat = [&](int64_t cnt, const double* a, const double* b, int slot) {
+            hipLaunchKernelGGL(k_logabs_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, cnt, a, b, partials.p);
+            hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, slots + slot);
+            hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p + kRedBlocks, kRedBlocks, slots + slot + 1);
+        };
+        logstat(n, ch.p, nullptr, 8);
+        logstat(m, loh.p, hih.p, 10);
+    }
+    double hs[12] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     KTN_HIP(hipMemcpyAsync(hs, slots, sizeof(hs), hipMemcpyDeviceToHost, stream));
     double epi_b = 0.0;                                 // b_ref of the working form: the objective constant it carries
     if (w_shift) KTN_HIP(hipMemcpyAsync(&epi_b, epi_scal.p, sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -2168,7 +2184,11 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     const double nc2_tol = w_shift ? hs[6] : nc2;       // (the working cost carries a_ref: not the scale the dual residual is judged on)
     double nb2 = (m > 0) ? hs[4] + hs[5] : 0.0;
     allreduce_host(&nb2, 1, 0);
-    const double omega_ref = (nc2 > 0.0 && nb2 > 0.0) ? std::sqrt(nc2 / nb2) : 1.0;
+    double omega_ref = (nc2 > 0.0 && nb2 > 0.0) ? std::sqrt(nc2 / nb2) : 1.0;
+    if (robust && hs[9] > 0.0 && hs[11] > 0.0) {
+        omega_ref = std::sqrt(hs[9] / hs[11]) * std::exp(hs[8] / hs[9] - hs[10] / hs[11]);
+        stats["lp_omega_robust"] += 1.0;
+    }
     double om = (have_omega && mode == 0) ? omega : omega_ref;
     const double rho = 1.0;
     const double cinf_scale = 1.0;

@@ -1849,6 +1849,26 @@ __global__ __launch_bounds__(kBlock) void k_dot_partial(int64_t n, const double*
         partials[blockIdx.x] = v;
     }
 }
+// partials[b] = sum of log|a_i| (and |b_i|, b optional) over the finite non-zero entries, partials[gridDim + b] = their count:
+// a magnitude statistic that a handful of outliers cannot move (see Engine::lp_solve_core, the initial primal weight)
+__global__ __launch_bounds__(kBlock) void k_logabs_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                                           double* __restrict__ partials) {
+    double ls = 0.0, cnt = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double u = fabs(a[i]);
+        if (u > 0.0 && isfinite(u)) { ls += log(u); cnt += 1.0; }
+        if (b) { const double v = fabs(b[i]); if (v > 0.0 && isfinite(v)) { ls += log(v); cnt += 1.0; } }
+    }
+    __shared__ double sh[2][kBlock / 64];
+    ls = group_sum<64>(ls); cnt = group_sum<64>(cnt);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = ls; sh[1][threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double u = 0.0, v = 0.0;
+        for (int k = 0; k < kBlock / 64; ++k) { u += sh[0][k]; v += sh[1][k]; }
+        partials[blockIdx.x] = u; partials[gridDim.x + blockIdx.x] = v;
+    }
+}
 // partials[b] = sum of (a_i d_i)^2: the squared norm of a vector in scaled coordinates without materialising it
 __global__ __launch_bounds__(kBlock) void k_scaled_sq_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ d,
                                                               double* __restrict__ partials) {
