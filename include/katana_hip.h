@@ -129,7 +129,7 @@ typedef struct {
                                        many of the deepest (largest g - ub / lb - g) get a cut in this iteration; the stop
                                        rule still needs EVERY row within f_tol.  0 = cut every violated row            */
     int64_t cut_cap_min;    /* 10000                                                                                    */
-    double  lp_stag_factor; /* 100     primal-stagnation exit of the LP: rows feasible, primal objective flat over three checks,
+    double  lp_stag_factor; /* 300     primal-stagnation exit of the LP: rows feasible, primal objective flat over two checks,
                                        gap within lp_stag_factor * tolerance (the dual of a degenerate LP crawls long after
                                        the primal has converged), and a row violation that has stalled below 2x the row
                                        tolerance with everything else converged is accepted; 0 = only the full criteria      */

@@ -153,6 +153,7 @@ struct LpResult {
     double pobj = 0.0, dobj = 0.0, row_viol = 0.0, gap = 0.0;
     double dres_rel = 0.0;          // dual residual over (1 + ||c||): what the solve's gap tolerance is compared with
     bool exact = false;             // solved by the exact small-LP kernel: no tolerance tightening needed
+    bool stag_exit = false;         // ended through the primal-stagnation exit (objective flat, gap within lp_stag_factor x tolerance)
 };
 
 struct Engine {
@@ -2310,6 +2311,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
                                      std::fabs(pviol - pviol_h[1]) <= 0.02 * pviol && std::fabs(pviol - pviol_h[2]) <= 0.02 * pviol;
                 if (flat && (pviol <= tol_p || plateau) && gap <= stag * tol_g && dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2_tol))) {
                     done = true;
+                    R.stag_exit = true;
                     stats["lp_stagnation_exits"] += 1.0;
                 }
             }
@@ -2436,6 +2438,9 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     if (prm.profile) ev_flush();
     stats["pdhg_iters"] += (double)it;
     stats["lp_solves"] += 1.0;
+    // (the quantities Engine::step's floor rule reads: a host-driven loop over the same entry points -- distributed.py -- needs them too)
+    stats["lp_last_row_viol"] = R.row_viol; stats["lp_last_gap"] = R.gap; stats["lp_last_dres_rel"] = R.dres_rel;
+    stats["lp_last_stag_exit"] = R.stag_exit ? 1.0 : 0.0;
     stats["lp_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return R;
 }
@@ -2602,7 +2607,10 @@ void Engine::step(int32_t* done) {
     // the LP itself was solved to the floor tolerance -- by request, or because the last check of a looser solve
     // happens to meet the floor tolerances already (then the re-solve would return this very point)
     const double floor_g = std::min(std::max(floor_p, prm.lp_gap_floor), prm.lp_gap_cap);
-    const bool at_floor = R.row_viol <= floor_p && R.gap <= floor_g && R.dres_rel <= floor_g;
+    // (... or ended through the stagnation exit with a gap the floor-tolerance solve would accept through that same exit: it
+    //  would return after its first two checks with this very point -- 34 iterations and a setup on cfg3)
+    const bool at_floor = R.row_viol <= floor_p && R.dres_rel <= floor_g &&
+                          (R.gap <= floor_g || (R.stag_exit && prm.lp_stag_factor > 0.0 && R.gap <= prm.lp_stag_factor * floor_g));
     if (sat_now && !R.exact && tol_p > floor_p * (1.0 + 1e-12) && !at_floor) last_maxviol = 0.0;
     else { allsat = sat_now; if (sat_now && tol_p > floor_p * (1.0 + 1e-12) && !R.exact) stats["floor_resolves_skipped"] += 1.0; }
     const double obj = objval;                                           // model.jl:287-289
@@ -2781,7 +2789,7 @@ void ktn_default_params(ktn_params* p) {
     p->purge_age = 2; p->purge_margin = 1e-3; p->purge_min_frac = 0.05; p->purge_min_rows = 2000;
     p->lp_dense_after = 5000;
     p->cut_cap_factor = 1.0; p->cut_cap_min = 10000;
-    p->lp_stag_factor = 100.0;
+    p->lp_stag_factor = 300.0;
     p->lp_ruiz_warm = 0; p->lp_tiled_nnz = 4000000; p->lp_near_check = 7; p->dedupe_eps = 1e-6;
     p->polish_factor = 1e-3; p->polish_max_var = 32; p->polish_max_iter = 30;
     p->epi_shift = 1;

@@ -237,7 +237,14 @@ class ShardedKatanaModel:
             self._status = "Error"
             return True
         self.last_maxviol = maxviol
-        if nviol == 0 and tol_p > floor_p * (1 + 1e-12):
+        # Engine::step's floor rule: satisfied at a loosely solved LP only counts when that solve already meets the floor
+        # tolerances (or left through the stagnation exit with a gap the floor-tolerance solve would accept the same way)
+        floor_g = min(max(floor_p, self.tol["gfloor"]), self.tol["gcap"])
+        stag = self.m.params.lp_stag_factor
+        gap = self.m.stat("lp_last_gap")
+        at_floor = (self.m.stat("lp_last_row_viol") <= floor_p and self.m.stat("lp_last_dres_rel") <= floor_g and
+                    (gap <= floor_g or (self.m.stat("lp_last_stag_exit") > 0 and stag > 0 and gap <= stag * floor_g)))
+        if nviol == 0 and tol_p > floor_p * (1 + 1e-12) and not at_floor:
             self.last_maxviol = 0.0                                # satisfied at a loosely solved LP: tighten first
         else:
             self.allsat = nviol == 0

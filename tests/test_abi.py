@@ -133,7 +133,7 @@ def test_binding_structs_have_the_library_layout():
     p = L.KtnParams()
     L.lib().ktn_default_params(C.byref(p))
     # the last fields of the struct read back their documented defaults: the mirror is aligned end to end
-    assert (p.f_tol, p.iter_cap, p.purge_min_rows, p.lp_dense_after, p.cut_cap_factor, p.cut_cap_min, p.lp_stag_factor) == (1e-6, 10000, 2000, 5000, 1.0, 10000, 100.0)
+    assert (p.f_tol, p.iter_cap, p.purge_min_rows, p.lp_dense_after, p.cut_cap_factor, p.cut_cap_min, p.lp_stag_factor) == (1e-6, 10000, 2000, 5000, 1.0, 10000, 300.0)
 
 
 def test_host_side_address_sanitizer_harness_of_the_abi_layer():
