@@ -2290,8 +2290,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         primal_ok = (pviol <= tol_p) && (dres * cinf_scale <= tol_g * (1.0 + std::sqrt(nc2_tol)));
         // Primal-stagnation exit (lp_stag_factor).  On LPs with degenerate duals the primal part converges within a few
         // hundred iterations while the duality gap crawls for 10 000 more: stop when the rows are
-        // feasible to tol_p, the dual residual is converged, the primal objective has not moved by more than 0.1 tol_g
-        // over the last three checks, and the gap is certified to lp_stag_factor * tol_g.
+        // feasible to tol_p, the dual residual is converged, the primal objective has not moved by more than 0.4 tol_g
+        // over the last two checks, and the gap is certified to lp_stag_factor * tol_g.
         {
             const double stag = prm.lp_stag_factor;
             if (stag > 0.0 && mode == 0 && !done) {
@@ -2301,8 +2301,13 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
                 //  96 / 32 / 8 seeds, objective errors, the 82 reference models, 240 fuzz models and the 48-shape matrix
                 //  unchanged.  KTN_STAG_CHECKS=3 restores the longer window.)
                 static const int stag_checks = std::getenv("KTN_STAG_CHECKS") ? std::atoi(std::getenv("KTN_STAG_CHECKS")) : 2;
-                const bool flat = std::fabs(pobj - pobj_h[0]) <= 0.1 * tol_g * scale && std::fabs(pobj - pobj_h[1]) <= 0.1 * tol_g * scale &&
-                                  (stag_checks < 3 || std::fabs(pobj - pobj_h[2]) <= 0.1 * tol_g * scale);
+                // ("flat" = within 0.4 tol_g; 0.1 until round 3.  The exit decides whether x* is a good separation point, not
+                //  the stop of the ECP loop, and tol_g itself is the accuracy asked of this solve: -12 % PDHG iterations on
+                //  cfg3 over 96 seeds, -9 % on cfg4, cfg2 unchanged, worst objective error 5e-7 of the 1e-6 allowed, the GPU
+                //  suite, fuzz set and shape matrix unchanged.  KTN_FLAT_FACTOR overrides.)
+                static const double flat_f = std::getenv("KTN_FLAT_FACTOR") ? std::atof(std::getenv("KTN_FLAT_FACTOR")) : 0.4;
+                const bool flat = std::fabs(pobj - pobj_h[0]) <= flat_f * tol_g * scale && std::fabs(pobj - pobj_h[1]) <= flat_f * tol_g * scale &&
+                                  (stag_checks < 3 || std::fabs(pobj - pobj_h[2]) <= flat_f * tol_g * scale);
                 // (a row violation that sits on a plateau -- unchanged to 2 % over three checks -- within the stalled-row allowance
                 //  below counts as feasible here: cfg4 seed 2 idled 23 000 iterations at 3.098e-7 against tol_p = 3.0e-7 with the
                 //  objective flat and the gap at 3 tol_g, so that neither exit applied)
