@@ -11,11 +11,17 @@ f_tol) the engine is reset to its post-loadproblem! state and the next step star
 so K steps are K consecutive iterations of back-to-back solves.  Inputs are resident in HBM before
 the timed region (ktn_loadproblem copies them once).
 
-With --gpus N > 1 (one rank per GPU, torch.distributed.run) the workload is BASELINE.json configs[3] ("cfg4": 1e6
-exp/log rows) with the LP ROW-SHARDED over the ranks (katana.jl_amd/distributed.py::RowShardedKatanaModel): every rank
-sweeps its block of NL rows and keeps its own cuts, A'y costs one RCCL all-reduce of an n-vector per PDHG iteration.
-The line then also carries the per-phase split and, for the strong-scaling ratio, the same workload timed on rank 0's
-GPU alone in the same run.
+With --gpus N > 1 (one rank per GPU, torch.distributed.run) the workload stays the SAME (strong scaling: the per-N values
+are one curve).  How the path is split depends on the workload (--lp-layout auto):
+  replicated   cfg3 and smaller: the NL rows are block-sharded over the ranks, every rank sweeps its block at x*, the cuts of
+               a sweep travel in ONE device-resident RCCL all-gather per ECP iteration and every rank appends all of them, in
+               rank order, to its own copy of the LP (katana.jl_amd/distributed.py::ShardedKatanaModel; north_star's design).
+               A cfg3 PDHG iteration is two launch-floor-bound kernels (14 us): there is nothing in it a second GPU can take.
+  row-sharded  --workload cfg4 (BASELINE.json configs[3], 1e6 exp/log rows): the LP ROW-SHARDED over the ranks
+               (RowShardedKatanaModel): every rank keeps its own cuts, A'y costs one RCCL all-reduce of an n-vector per
+               PDHG iteration.
+The line then also carries the per-phase split, the measured latency of one all-reduce of an n-vector on the fabric and the
+same workload timed on rank 0's GPU alone in the same run.
 
 Prints ONE JSON line (rank 0).  `value` = ECP iterations / second, whole job.
   roofline     -- the dominant kernel = whichever of k_pdhg_x / k_pdhg_y has the larger total time in the run
@@ -85,7 +91,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=33)
     ap.add_argument("--warmup", type=int, default=11)
-    ap.add_argument("--workload", default=None, help="default: cfg3 on one GPU, cfg4 on several")
+    ap.add_argument("--workload", default="cfg3", help="cfg3 (BASELINE.json's metric), cfg2, cfg4, cfg5, cfg3_qp ...")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-baseline-mt", action="store_true", help="skip the second CPU line (HiGHS default threading)")
@@ -93,10 +99,14 @@ def parse():
     ap.add_argument("--no-sweep-roofline", action="store_true")
     ap.add_argument("--no-spmv-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-scale", type=float, default=1.0, help="1.0 = the configuration of `value`; 0.5 = half scale (quick)")
-    ap.add_argument("--replicated-lp", action="store_true", help="N > 1: the round-1 design (replicated LP, all-gather of cuts)")
+    ap.add_argument("--lp-layout", choices=("auto", "replicated", "row-sharded"), default="auto",
+                    help="N > 1: replicated LP + all-gather of cuts, or row-sharded LP + all-reduce per PDHG iteration; "
+                         "auto = row-sharded for cfg4, replicated otherwise")
+    ap.add_argument("--replicated-lp", action="store_true", help="same as --lp-layout replicated")
     a = ap.parse_args()
-    if a.workload is None:
-        a.workload = "cfg3" if a.gpus == 1 else "cfg4"
+    if a.lp_layout == "auto":
+        a.lp_layout = "row-sharded" if a.workload == "cfg4" else "replicated"
+    a.replicated_lp = a.replicated_lp or a.lp_layout == "replicated"
     return a
 
 
