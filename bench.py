@@ -103,6 +103,9 @@ def parse():
                     help="N > 1: replicated LP + all-gather of cuts, or row-sharded LP + all-reduce per PDHG iteration; "
                          "auto = row-sharded for cfg4, replicated otherwise")
     ap.add_argument("--replicated-lp", action="store_true", help="same as --lp-layout replicated")
+    ap.add_argument("--transport", choices=("auto", "rccl", "ipc", "callback"), default="auto",
+                    help="row-sharded layout: RCCL all-reduce (default over nccl), peer-buffer transport (ktn_dist_init_ipc), or the "
+                         "host callback (gloo rehearsals)")
     a = ap.parse_args()
     if a.lp_layout == "auto":
         a.lp_layout = "row-sharded" if a.workload == "cfg4" else "replicated"
@@ -274,7 +277,7 @@ def main():
         model = ShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=local_rank), inst, rank, world, dist)
     elif world > 1:
         from katana_jl_amd.distributed import RowShardedKatanaModel
-        model = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=local_rank), inst, rank, world, dist)
+        model = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=local_rank), inst, rank, world, dist, transport=args.transport)
     else:
         model = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, device=local_rank))
         model.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense,
@@ -500,6 +503,11 @@ def main():
                  "allreduce_calls": phases["allreduce_calls"], "allreduce_MB": phases["allreduce_bytes"] / 1e6,
                  "allreduce_n_vector_us": ar_us, "exchange": "none (row-sharded LP: every rank keeps its own cuts)"
                  if not args.replicated_lp else "all-gather of cut blocks", "lp_rows_rank0": model.lp_num_rows()}
+        if not args.replicated_lp:
+            # the same vector through the engine's own transport (RCCL on its stream / peer buffers / host callback), and its
+            # self-check: the sum and the max every rank can compute for itself
+            eng_us, eng_dev = model.allreduce_probe(inst.n + 1, 50)
+            multi.update({"transport": model.transport, "engine_allreduce_n_vector_us": eng_us, "engine_allreduce_deviation": eng_dev})
         if rank == 0:
             one = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, device=local_rank))
             one.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense,
@@ -527,7 +535,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else (
                            "nl-rows sharded x%d, replicated LP, all-gather of cuts" % world if args.replicated_lp else
                            "rows sharded x%d (linear rows and NL rows by blocks, cuts stay on their rank), x replicated, "
-                           "one RCCL all-reduce of an n-vector per PDHG iteration" % world)},
+                           "one all-reduce of an n-vector per PDHG iteration (transport: %s)" % (world, model.transport))},
             "wall_to_ftol_s": wall_to_ftol, "ecp_iters_to_ftol": iters_to_ftol, "status": status, "objective": obj,
             "planted_objective": inst.opt_obj, "objective_relerr": abs(obj - inst.opt_obj) / max(1.0, abs(inst.opt_obj)),
             "pdhg_iters_per_step": pdhg_timed / args.steps, "solves_in_timed_region": len(solves),

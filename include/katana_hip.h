@@ -366,11 +366,27 @@ int ktn_optimize_blocks(ktn_handle h, int32_t cut_capacity);
  *   ktn_dist_init_rccl  : collectives = ncclAllReduce on the engine's stream (RCCL over xGMI)
  *   ktn_dist_init_callback : collectives through the caller: cb(user, host_buf, count, op) must all-reduce host_buf in
  *                         place over the ranks (op 0: sum, 1: max) and return 0 -- the engine stages through the host.
- *                         For tests (gloo; several ranks sharing one GPU, which RCCL does not allow).                  */
+ *                         For tests (gloo; several ranks sharing one GPU, which RCCL does not allow).
+ *   ktn_dist_ipc_export + ktn_dist_init_ipc : peer-buffer transport.  Every rank exposes a buffer of 2 x `capacity` doubles
+ *                         (capacity >= the LP's column count) and a page of flag words; export returns their two
+ *                         hipIpcMemHandle_t (2 x 64 bytes: data, flags); the caller gathers the `world` pairs in rank order
+ *                         (any byte transport: torch.distributed.all_gather, MPI, a file) and hands them to init, which maps
+ *                         the peers' buffers (xGMI peer access).  An all-reduce is then: partial written into the exposed slot,
+ *                         one single-workgroup kernel that signals every rank and waits for every rank (bounded spin:
+ *                         KTN_IPC_TIMEOUT_S, default 20 s, then KTN_E_HIP), and the consumer adding up the world's slots in rank
+ *                         order itself -- no ring, no intermediate copy, identical bits on every rank.  2 <= world <= 8, one
+ *                         node.  Ranks must destroy their handles together (ktn_destroy runs one last barrier).
+ *   ktn_dist_allreduce_probe : collective self-test / timing of whatever transport the handle has: all-reduces (sum, max) a
+ *                         vector whose result every rank can compute itself and returns the largest deviation, then the
+ *                         mean time of `reps` sum all-reduces of n doubles.                                              */
 typedef int (*ktn_allreduce_cb)(void* user, double* host_buf, int64_t count, int32_t op);
 int ktn_dist_unique_id(char* out128);
 int ktn_dist_init_rccl(ktn_handle h, const char* uid128, int32_t rank, int32_t world);
 int ktn_dist_init_callback(ktn_handle h, int32_t rank, int32_t world, ktn_allreduce_cb cb, void* user);
+#define KTN_IPC_HANDLE_BYTES 64
+int ktn_dist_ipc_export(ktn_handle h, int32_t rank, int32_t world, int64_t capacity, char* out_handles128);
+int ktn_dist_init_ipc(ktn_handle h, int32_t rank, int32_t world, const char* all_handles /* world x 128 bytes */);
+int ktn_dist_allreduce_probe(ktn_handle h, int64_t n, int32_t reps, double* usec_per_call, double* max_abs_err);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,9 @@ PROTOTYPES = {
     "ktn_dist_unique_id": (c_i32, [C.c_char_p]),
     "ktn_dist_init_rccl": (c_i32, [C.c_void_p, C.c_char_p, c_i32, c_i32]),
     "ktn_dist_init_callback": (c_i32, [C.c_void_p, c_i32, c_i32, C.c_void_p, C.c_void_p]),
+    "ktn_dist_ipc_export": (c_i32, [C.c_void_p, c_i32, c_i32, c_i64, C.c_char_p]),
+    "ktn_dist_init_ipc": (c_i32, [C.c_void_p, c_i32, c_i32, C.c_char_p]),
+    "ktn_dist_allreduce_probe": (c_i32, [C.c_void_p, c_i64, c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ktn_lp_append_rows": (c_i32, [C.c_void_p, c_i64, P(c_i64), P(c_i32), P(c_f64), P(c_f64), P(c_f64)]),
 }
 

@@ -415,6 +415,7 @@ struct Engine {
     }
     ~Engine() {
         if (dist.comm) (void)ncclCommDestroy(dist.comm);
+        ipc_release();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
         if (h_chk) (void)hipHostFree(h_chk);
@@ -436,14 +437,55 @@ struct Engine {
         ktn_allreduce_cb cb = nullptr;
         void* user = nullptr;
         std::vector<double> hbuf;
+        // peer-buffer transport (ktn_dist_ipc_export / ktn_dist_init_ipc; kernels.hpp "peer-buffer transport")
+        struct Ipc {
+            bool on = false;
+            int64_t cap = 0;                          // doubles per slot
+            double* data = nullptr;                   // this rank's exposed buffer: 2 slots
+            unsigned long long* flags = nullptr;      // this rank's flag words (uncached)
+            void* opened[2 * kIpcMaxRanks] = {};      // what hipIpcOpenMemHandle returned (to close)
+            IpcPeers P = {};
+            unsigned long long epoch = 0;
+            long long timeout_ticks = 0;
+            int* h_err = nullptr;                     // pinned, device-mapped: a timed-out spin reports here
+            int* h_err_dev = nullptr;
+        } ipc;
     } dist;
+    // the slot the NEXT all-reduce publishes from: a producer may write its partial straight into it
+    int64_t ipc_off() const { return (int64_t)(dist.ipc.epoch & 1ull) * dist.ipc.cap; }
+    double* ipc_slot() const { return dist.ipc.data + ipc_off(); }
+    void ipc_check() {
+        if (dist.ipc.on && dist.ipc.h_err && *dist.ipc.h_err != 0) {
+            const int src = *dist.ipc.h_err - 1;
+            throw Error(KTN_E_HIP, "peer-buffer transport: rank " + std::to_string(dist.rank) + " timed out waiting for rank " + std::to_string(src));
+        }
+    }
+    // signal "my slot of this epoch is complete" to every rank and wait for theirs; returns the slot offset to read
+    int64_t ipc_barrier() {
+        const int64_t off = ipc_off();
+        dist.ipc.epoch += 1;
+        hipLaunchKernelGGL(k_ipc_barrier, dim3(1), dim3(64), 0, stream, dist.ipc.P, dist.rank, dist.world, dist.ipc.epoch,
+                           dist.ipc.timeout_ticks, dist.ipc.h_err_dev);
+        return off;
+    }
+    void ipc_release();
     DBuf<double> d_red;            // small device scratch for scalar reductions
     bool row_sharded() const { return dist.world > 1 || dist.force; }
     void allreduce(double* d, size_t n, int op) {          // in place; op 0: sum, 1: max
         if (!row_sharded() || n == 0) return;
         stats["allreduce_calls"] += 1.0;
         stats["allreduce_bytes"] += 8.0 * (double)n;
-        if (dist.comm) {
+        if (dist.ipc.on) {
+            KTN_REQUIRE((int64_t)n <= dist.ipc.cap, "peer-buffer transport: vector longer than the exposed slot");
+            size_t ea = 0, eb = 0;
+            if (prm.profile) { ea = ev_get(); eb = ev_get(); KTN_HIP(hipEventRecord(ev_pool[ea], stream)); }
+            if (d != ipc_slot()) KTN_HIP(hipMemcpyAsync(ipc_slot(), d, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            const int64_t off = ipc_barrier();
+            if (op) hipLaunchKernelGGL((k_ipc_reduce<1>), dim3(ceil_div((int64_t)n, kBlock)), dim3(kBlock), 0, stream, (int64_t)n, dist.ipc.P, dist.world, off, d);
+            else hipLaunchKernelGGL((k_ipc_reduce<0>), dim3(ceil_div((int64_t)n, kBlock)), dim3(kBlock), 0, stream, (int64_t)n, dist.ipc.P, dist.world, off, d);
+            check_launch();
+            if (prm.profile) { KTN_HIP(hipEventRecord(ev_pool[eb], stream)); ev_recs.push_back({3, ea, eb, 8.0 * (double)n}); }
+        } else if (dist.comm) {
             size_t ea = 0, eb = 0;
             if (prm.profile) { ea = ev_get(); eb = ev_get(); KTN_HIP(hipEventRecord(ev_pool[ea], stream)); }
             const ncclResult_t r = ncclAllReduce(d, d, n, ncclDouble, op ? ncclMax : ncclSum, dist.comm, stream);
@@ -468,6 +510,7 @@ struct Engine {
         allreduce(d_red.p, (size_t)k, op);
         KTN_HIP(hipMemcpyAsync(v, d_red.p, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, stream));
         sync();
+        ipc_check();
     }
 
     // ------------------------------------------------------------------ profiling ---
@@ -1821,13 +1864,25 @@ void Engine::launch_x(const SpMat& AT, double tau, double w, double rho, bool up
     const int64_t n = n_lp;
     if (row_sharded()) {
         // local partial of A'y, summed over the ranks, then the element-wise primal step on the replicated x
-        if (M == 0) LAUNCH_1(k_fill, n, stream, n, pv.p, 0.0);
+        // (peer-buffer transport: the partial is written straight into the exposed slot, and the primal step adds up the
+        //  ranks' slots itself -- spmv, one single-workgroup barrier kernel, prox: no reduction pass, no copy)
+        const bool ipc = dist.ipc.on && n <= dist.ipc.cap;
+        double* part = ipc ? ipc_slot() : pv.p;
+        if (M == 0) LAUNCH_1(k_fill, n, stream, n, part, 0.0);
         if (tiled_on && M > 0) {                          // this rank's block is large: its partial A_r'y_r from the tiled copy
             launch_tiled(tAT, n, M, yh.p, e0);
-            hipExtLaunchKernelGGL(k_tile_vec, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, n, tAT.pcnt.p, tpart.p, pv.p);
+            hipExtLaunchKernelGGL(k_tile_vec, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, n, tAT.pcnt.p, tpart.p, part);
         }
-        else if (e0) LAUNCH_G_EV(grp_cols, k_spmv, n, stream, e0, e1, n, AT, yh.p, pv.p);
-        else LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, yh.p, pv.p);
+        else if (e0) LAUNCH_G_EV(grp_cols, k_spmv, n, stream, e0, e1, n, AT, yh.p, part);
+        else LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, yh.p, part);
+        if (ipc) {
+            stats["allreduce_calls"] += 1.0;
+            stats["allreduce_bytes"] += 8.0 * (double)n;
+            const int64_t off = ipc_barrier();
+            if (update) LAUNCH_1(k_x_prox_ipc<true>, n, stream, n, dist.ipc.P, dist.world, off, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+            else LAUNCH_1(k_x_prox_ipc<false>, n, stream, n, dist.ipc.P, dist.world, off, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+            return;
+        }
         allreduce(pv.p, (size_t)n, 0);
         if (update) LAUNCH_1(k_x_prox<true>, n, stream, n, pv.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
         else LAUNCH_1(k_x_prox<false>, n, stream, n, pv.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
@@ -2271,6 +2326,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         } else {
             KTN_HIP(hipMemcpyAsync(q, chkout.p, sizeof(q), hipMemcpyDeviceToHost, stream));
             sync();
+            ipc_check();
         }
         if (prm.profile) ev_flush();
         const double dyAdx = q[0], dy2 = q[1], dobj_rows = q[2], dy0sq = q[3], yt2 = q[4], pviol = q[12];
@@ -2744,6 +2800,23 @@ double Engine::objective_certificate() {
     return (D == D) ? std::max(D, 0.0) : kInf;
 }
 
+// Leave the peer-buffer transport: one last barrier (after it no peer kernel of an earlier epoch can still be reading this
+// rank's slots, and this rank reads nobody's), then unmap the peers' buffers and free the exposed ones.
+void Engine::ipc_release() {
+    auto& I = dist.ipc;
+    if (I.on) {
+        (void)hipSetDevice(device);
+        I.timeout_ticks = std::max<long long>(I.timeout_ticks / 10, 1);       // (a peer that is gone already must not hold the teardown up)
+        ipc_barrier();
+        (void)hipStreamSynchronize(stream);
+        I.on = false;
+    }
+    for (void*& p : I.opened) if (p) { (void)hipIpcCloseMemHandle(p); p = nullptr; }
+    if (I.data) { (void)hipFree(I.data); I.data = nullptr; }
+    if (I.flags) { (void)hipFree(I.flags); I.flags = nullptr; }
+    if (I.h_err) { (void)hipHostFree(I.h_err); I.h_err = nullptr; I.h_err_dev = nullptr; }
+}
+
 void Engine::end() {
     soltime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();   // model.jl:311
     if (status == KTN_STATUS_ERROR || status == KTN_STATUS_UNBOUNDED) return;
@@ -3202,6 +3275,109 @@ int ktn_dist_init_callback(ktn_handle h, int32_t rank, int32_t world, ktn_allred
         KTN_REQUIRE(!e->loaded, "ktn_dist_init_*: call before loadproblem");
         KTN_REQUIRE(world >= 1 && rank >= 0 && rank < world && (world == 1 || cb), "ktn_dist_init_callback: bad arguments");
         e->dist.rank = rank; e->dist.world = world; e->dist.cb = cb; e->dist.user = user;
+        return KTN_OK;
+    })
+}
+
+// peer-buffer transport: export this rank's buffers, then map everybody's (kernels.hpp "peer-buffer transport")
+int ktn_dist_ipc_export(ktn_handle h, int32_t rank, int32_t world, int64_t capacity, char* out_handles128) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        auto& I = e->dist.ipc;
+        static_assert(sizeof(hipIpcMemHandle_t) == KTN_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+        KTN_REQUIRE(!e->loaded, "ktn_dist_init_*: call before loadproblem");
+        KTN_REQUIRE(out_handles128 && world >= 2 && world <= ktn::kIpcMaxRanks && rank >= 0 && rank < world && capacity >= 64,
+                    "ktn_dist_ipc_export: bad arguments (2 <= world <= 8, capacity >= 64)");
+        KTN_REQUIRE(I.data == nullptr, "ktn_dist_ipc_export: called twice");
+        KTN_HIP(hipSetDevice(e->device));
+        I.cap = capacity;
+        KTN_HIP(hipMalloc((void**)&I.data, sizeof(double) * 2 * (size_t)capacity));
+        // flag words: uncached device memory (every load and store goes to memory: what a peer wrote is what a spin reads)
+        if (hipExtMallocWithFlags((void**)&I.flags, 4096, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            KTN_HIP(hipExtMallocWithFlags((void**)&I.flags, 4096, hipDeviceMallocFinegrained));
+        }
+        KTN_HIP(hipMemsetAsync(I.data, 0, sizeof(double) * 2 * (size_t)capacity, e->stream));
+        KTN_HIP(hipMemsetAsync(I.flags, 0, 4096, e->stream));
+        KTN_HIP(hipHostMalloc((void**)&I.h_err, 64, hipHostMallocMapped));
+        *I.h_err = 0;
+        KTN_HIP(hipHostGetDevicePointer((void**)&I.h_err_dev, I.h_err, 0));
+        e->sync();
+        hipIpcMemHandle_t hd, hf;
+        KTN_HIP(hipIpcGetMemHandle(&hd, I.data));
+        KTN_HIP(hipIpcGetMemHandle(&hf, I.flags));
+        std::memcpy(out_handles128, &hd, KTN_IPC_HANDLE_BYTES);
+        std::memcpy(out_handles128 + KTN_IPC_HANDLE_BYTES, &hf, KTN_IPC_HANDLE_BYTES);
+        e->dist.rank = rank; e->dist.world = world;
+        return KTN_OK;
+    })
+}
+int ktn_dist_init_ipc(ktn_handle h, int32_t rank, int32_t world, const char* all_handles) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        auto& I = e->dist.ipc;
+        KTN_REQUIRE(!e->loaded, "ktn_dist_init_*: call before loadproblem");
+        KTN_REQUIRE(all_handles && I.data && rank == e->dist.rank && world == e->dist.world, "ktn_dist_init_ipc: ktn_dist_ipc_export first, same rank / world");
+        KTN_HIP(hipSetDevice(e->device));
+        for (int r = 0; r < world; ++r) {
+            if (r == rank) { I.P.data[r] = I.data; I.P.flags[r] = I.flags; continue; }
+            hipIpcMemHandle_t hd, hf;
+            std::memcpy(&hd, all_handles + (size_t)r * 2 * KTN_IPC_HANDLE_BYTES, KTN_IPC_HANDLE_BYTES);
+            std::memcpy(&hf, all_handles + (size_t)r * 2 * KTN_IPC_HANDLE_BYTES + KTN_IPC_HANDLE_BYTES, KTN_IPC_HANDLE_BYTES);
+            void* pd = nullptr; void* pf = nullptr;
+            KTN_HIP(hipIpcOpenMemHandle(&pd, hd, hipIpcMemLazyEnablePeerAccess));
+            I.opened[2 * r] = pd;
+            KTN_HIP(hipIpcOpenMemHandle(&pf, hf, hipIpcMemLazyEnablePeerAccess));
+            I.opened[2 * r + 1] = pf;
+            I.P.data[r] = (double*)pd; I.P.flags[r] = (unsigned long long*)pf;
+        }
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+        const char* ts = std::getenv("KTN_IPC_TIMEOUT_S");
+        const double secs = ts ? std::atof(ts) : 20.0;
+        I.timeout_ticks = (long long)(secs * 1e3 * (double)khz);
+        I.epoch = 0;
+        I.on = true;
+        return KTN_OK;
+    })
+}
+// One all-reduce of an n-vector through whatever transport the handle has, `reps` times: mean time per call and the largest
+// deviation from the sum every rank can compute for itself (in round k rank r contributes k (r + 1) + 1e-3 (j mod 1000)).  Collective call.
+int ktn_dist_allreduce_probe(ktn_handle h, int64_t n, int32_t reps, double* usec_per_call, double* max_abs_err) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->row_sharded() && n >= 1 && reps >= 1 && usec_per_call && max_abs_err, "ktn_dist_allreduce_probe: needs a transport (ktn_dist_init_*)");
+        KTN_HIP(hipSetDevice(e->device));
+        ktn::DBuf<double> v;
+        v.resize((size_t)n, e->stream);
+        const int w = e->dist.world;
+        std::vector<double> host((size_t)n);
+        double worst = 0.0;
+        // six rounds with different contents, sum and max alternating: every slot of the peer-buffer transport is reused with
+        // new data twice or more (a stale line anywhere on the way shows as a deviation)
+        for (int round = 0; round < 6; ++round) {
+            const int op = round & 1;
+            const double scale = (double)(round + 1);
+            hipLaunchKernelGGL(ktn::k_probe_fill, dim3(ktn::ceil_div(n, ktn::kBlock)), dim3(ktn::kBlock), 0, e->stream, n, v.p, scale * (double)(e->dist.rank + 1));
+            e->allreduce(v.p, (size_t)n, op);
+            KTN_HIP(hipMemcpyAsync(host.data(), v.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            e->sync();
+            e->ipc_check();
+            for (int64_t j = 0; j < n; ++j) {
+                const double t = 1e-3 * (double)(j % 1000);
+                const double want = op ? scale * (double)w + t : scale * 0.5 * (double)w * (double)(w + 1) + (double)w * t;
+                worst = std::max(worst, std::fabs(host[(size_t)j] - want));
+            }
+        }
+        hipLaunchKernelGGL(ktn::k_probe_fill, dim3(ktn::ceil_div(n, ktn::kBlock)), dim3(ktn::kBlock), 0, e->stream, n, v.p, 0.0);
+        e->allreduce(v.p, (size_t)n, 0);
+        e->sync();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps; ++i) e->allreduce(v.p, (size_t)n, 0);
+        e->sync();
+        e->ipc_check();
+        *usec_per_call = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (double)reps;
+        *max_abs_err = worst;
         return KTN_OK;
     })
 }

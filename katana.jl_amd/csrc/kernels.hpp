@@ -1311,6 +1311,70 @@ __global__ __launch_bounds__(kBlock) void k_chk_cols_vec(int64_t n, const double
     chk_block_store<kBlock, kChkColMask>(a, partials);
 }
 
+// ---- peer-buffer transport for the row-sharded LP (ktn_dist_init_ipc) -------------------------------------------------
+// Instead of a ring all-reduce (RCCL: 2 (w - 1) dependent hops for 0.8 MB) every rank EXPOSES its partial vector in a buffer
+// the other ranks have mapped (hipIpcOpenMemHandle: xGMI peer loads), tells them so, and each rank adds up all w partials
+// itself, in rank order -- the same sum, bit for bit, on every rank.  Per all-reduce: the producer writes straight into the
+// exposed slot, ONE single-workgroup kernel signals + waits (k_ipc_barrier), and the consumer (the primal step itself,
+// k_x_prox_ipc) reads the w slots.  Rules the protocol rests on:
+//   * data is only ever read by a kernel that STARTS after the barrier kernel of that epoch has ended, and was written by a
+//     kernel that ENDED before it started (stream order): visibility rides on kernel boundaries, never on a fence inside a
+//     running grid; peer reads are system-scope loads on top (no stale line of this GPU's L2s can serve them);
+//   * flags are monotone epoch counters in uncached memory, one word per (receiver, source): no reset, no ABA;
+//   * two slots alternate: a rank overwrites slot s at epoch e + 2 only after passing the barrier of epoch e + 1, which
+//     every peer enters after its reads of epoch e (stream order);
+//   * every spin is bounded (wall clock); a timeout is reported through *err (host-mapped) and turns into an error status.
+constexpr int kIpcMaxRanks = 8;
+struct IpcPeers {
+    double* data[kIpcMaxRanks];                    // rank r's exposed buffer: two slots of `cap` doubles
+    unsigned long long* flags[kIpcMaxRanks];       // rank r's flag words, one per source rank
+};
+__device__ __forceinline__ double ipc_load(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load((unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__global__ __launch_bounds__(64) void k_ipc_barrier(IpcPeers P, int rank, int world, unsigned long long epoch, long long timeout_ticks,
+                                                    int* __restrict__ err) {
+    const int t = threadIdx.x;
+    if (t >= world) return;
+    __hip_atomic_store(P.flags[t] + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);       // "my slot of this epoch is complete"
+    const long long t0 = (long long)wall_clock64();
+    while (__hip_atomic_load(P.flags[rank] + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+        if ((long long)wall_clock64() - t0 > timeout_ticks) { *err = 1 + t; break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+// out = sum (OP 0) or max (OP 1) over the ranks of their slot, in rank order
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_ipc_reduce(int64_t n, IpcPeers P, int world, int64_t off, double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    double s = ipc_load(P.data[0] + off + j);
+    for (int r = 1; r < world; ++r) {
+        const double v = ipc_load(P.data[r] + off + j);
+        s = OP ? fmax(s, v) : s + v;
+    }
+    out[j] = s;
+}
+// k_x_prox with A'y = the sum of the ranks' exposed partials
+template <bool UPDATE>
+__global__ __launch_bounds__(kBlock) void k_x_prox_ipc(int64_t n, IpcPeers P, int world, int64_t off, double* __restrict__ x,
+                                                       const double* __restrict__ x0, double* __restrict__ xt, double* __restrict__ xbar,
+                                                       const double* __restrict__ c, const double* __restrict__ l,
+                                                       const double* __restrict__ u, double tau, double w, double rho) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    double aty = ipc_load(P.data[0] + off + j);
+    for (int r = 1; r < world; ++r) aty += ipc_load(P.data[r] + off + j);
+    const double xv = x[j];
+    const double xtv = clampd(xv - tau * (c[j] - aty), l[j], u[j]);
+    if (UPDATE) { xbar[j] = 2.0 * xtv - xv; x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0[j]; }
+    else xt[j] = xtv;
+}
+__global__ __launch_bounds__(kBlock) void k_probe_fill(int64_t n, double* __restrict__ v, double base) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j < n) v[j] = base + 1e-3 * (double)(j % 1000);
+}
+
 // ================================================== LP: tiled SpMV for LPs beyond the caches =========================
 // (DESIGN.md section 4 "HBM-regime SpMV".)  In CSR form every 8-byte gather of the input vector is its own L1 miss and
 // drags a 128-byte line from L2; with tens of millions of entries that traffic, not the 12 B/entry matrix stream, is

@@ -332,8 +332,24 @@ class RowShardedKatanaModel:
         forced = world == 1 and dist is not None and bool(os.environ.get("KTN_FORCE_COLLECTIVE"))   # one-rank RCCL test
         if world > 1 or forced:
             if transport == "auto":
-                transport = "rccl" if dist.get_backend() == "nccl" else "callback"
-            if transport == "rccl":
+                transport = os.environ.get("KTN_DIST_TRANSPORT") or ("rccl" if dist.get_backend() == "nccl" else "callback")
+            if transport == "ipc":
+                # peer-buffer transport (include/katana_hip.h): export this rank's buffers, gather everybody's handles, map them
+                import torch
+                cap = int(inst.n) + 64                       # (+ epigraph column; the scalar reductions need far less)
+                mine = C.create_string_buffer(128)
+                L.check(h, lib.ktn_dist_ipc_export(h, rank, world, cap, mine))
+                dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+                t = torch.tensor(list(mine.raw), dtype=torch.uint8, device=dev)
+                got = [torch.zeros_like(t) for _ in range(world)]
+                dist.all_gather(got, t)
+                raw = b"".join(bytes(g.cpu().tolist()) for g in got)
+                L.check(h, lib.ktn_dist_init_ipc(h, rank, world, raw))
+                # self-test before any solve rests on it: a sum and a max every rank can check for itself
+                _, err = self.allreduce_probe(min(cap, 1 << 16), 2)
+                if not err <= 1e-9:
+                    raise RuntimeError("peer-buffer transport failed its self-test on rank %d: deviation %g" % (rank, err))
+            elif transport == "rccl":
                 import torch
                 uid = C.create_string_buffer(128)
                 if rank == 0:
@@ -352,6 +368,15 @@ class RowShardedKatanaModel:
 
     def __getattr__(self, name):                # getters, stepping interface, stats: those of the local handle
         return getattr(self.m, name)
+
+    def allreduce_probe(self, n, reps=20):
+        """(mean microseconds of one all-reduce of n doubles through this handle's transport, largest deviation of a sum / max
+        all-reduce from the value every rank can compute itself).  Collective call."""
+        import ctypes as C
+        from . import _lib as L
+        us, err = C.c_double(0.0), C.c_double(0.0)
+        L.check(self.m._h, self.m._lib.ktn_dist_allreduce_probe(self.m._h, int(n), int(reps), C.byref(us), C.byref(err)))
+        return us.value, err.value
 
     def numcuts_global(self):
         """cuts generated on all ranks (numcuts() is this rank's count; the linear rows are counted once, src/model.jl:77)"""

@@ -8,6 +8,7 @@ the single-GPU solve."""
 import os
 import socket
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -324,7 +325,7 @@ def test_row_sharded_iteration_equals_the_unsharded_one_over_gloo():
         assert np.array_equal(out[r][3], [3.0, -2.0, 14.0]) and np.array_equal(out[r][5], [2.0, 0.0, 7.0])
 
 
-def _worker_rowshard_gpu(rank, world, port, out, inst_kw, tiled=False):
+def _worker_rowshard_gpu(rank, world, port, out, inst_kw, tiled=False, transport="auto"):
     sys.path.insert(0, ROOT)
     if tiled:
         os.environ["KTN_TILED"] = "1"          # every LP of this process runs its steps and checks from the tiled copies
@@ -334,17 +335,20 @@ def _worker_rowshard_gpu(rank, world, port, out, inst_kw, tiled=False):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     inst = ktn.instances.make_instance(**inst_kw)
     # (a) one LP, tight tolerances: linear rows + the cuts of one sweep at a common point
-    m = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0, purge_age=0, cut_cap_factor=0.0), inst, rank, world, dist)
+    m = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0, purge_age=0, cut_cap_factor=0.0), inst, rank, world, dist,
+                              transport=transport)
     sep = ktn.KatanaHipSeparator(m.m); sep.initialize()
     sep.precompute(np.clip(inst.xhat + 0.7, inst.l_var, inst.u_var))
     sep.sweep(1e-6)
     st, it = m.lp_solve(1e-10, 1e-10)
     lp = (st, m.getobjval(), m.lp_num_rows(), m.stat("allreduce_calls"), m.transport)
     # (b) the whole ECP solve
-    m2 = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0), inst, rank, world, dist)
+    m2 = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0), inst, rank, world, dist, transport=transport)
     status = m2.optimize()
     out[rank] = (lp, status, m2.getobjval(), m2.getsolution(), m2.numiters(), m2.numcuts_global(), m2.lp_num_rows(),
-                 m.stat("lp_tiled_builds") + m2.stat("lp_tiled_builds"))
+                 m.stat("lp_tiled_builds") + m2.stat("lp_tiled_builds"), m2.stat("pdhg_iters"), m2.allreduce_probe(inst.n, 3))
+    dist.barrier()                              # peer-buffer transport: the ranks leave together
+    del m, m2
     dist.destroy_process_group()
 
 
@@ -397,6 +401,93 @@ def test_two_rank_row_sharded_lp_through_the_tiled_copies():
     assert out[0][2] == out[1][2] and np.array_equal(out[0][3], out[1][3]) and out[0][4] == out[1][4]
     assert abs(out[0][2] - inst.opt_obj) <= planted_obj_bound(inst)
     assert max_nl_violation(inst, out[0][3]) <= 1e-6 * (1 + 1e-6)
+
+
+@pytest.mark.gpu
+def test_two_rank_row_sharded_lp_over_the_peer_buffer_transport():
+    """2 processes on cuda:0, each mapping the other's exposed buffers (hipIpcGetMemHandle -> gloo all_gather of the handles ->
+    hipIpcOpenMemHandle): partials written into the exposed slot, one signal-and-wait kernel, sums taken by the consumer in rank
+    order.  With two ranks a + b is the same double whichever transport adds it, so the whole trajectory -- every LP, every
+    cut, the final x -- must equal the host-callback transport's bit for bit; the LP objective equals the single-handle LP's to
+    1e-9.  (What one GPU cannot show is the visibility of a PEER GPU's stores: the two processes share the L2s.  The
+    protocol's rules for that are in kernels.hpp "peer-buffer transport".)"""
+    import katana_jl_amd as ktn
+    from helpers import hip_load_instance, max_nl_violation, planted_obj_bound
+    world = 2
+    inst_kw = dict(n=400, m_nl=60, k=10, family="explog", seed=11)
+    out, ref = mp.Manager().dict(), mp.Manager().dict()
+    mp.spawn(_worker_rowshard_gpu, args=(world, _free_port(), out, inst_kw, False, "ipc"), nprocs=world, join=True)
+    mp.spawn(_worker_rowshard_gpu, args=(world, _free_port(), ref, inst_kw, False, "callback"), nprocs=world, join=True)
+    inst = ktn.instances.make_instance(**inst_kw)
+    one = hip_load_instance(ktn, inst, purge_age=0, cut_cap_factor=0.0, lp_dense_after=0)
+    sep = ktn.KatanaHipSeparator(one); sep.initialize()
+    sep.precompute(np.clip(inst.xhat + 0.7, inst.l_var, inst.u_var))
+    sep.sweep(1e-6)
+    st, _ = one.lp_solve(1e-10, 1e-10)
+    assert st == "Optimal"
+    for r in range(world):
+        lp, status = out[r][0], out[r][1]
+        assert lp[0] == "Optimal" and lp[4] == "ipc" and status == "Optimal" and lp[3] > 0
+        assert abs(lp[1] - one.getobjval()) <= 1e-9 * max(1.0, abs(one.getobjval()))
+        assert lp[1] == ref[r][0][1]                                                 # the LP: same bits as the callback transport
+        assert out[r][2] == ref[r][2] and np.array_equal(out[r][3], ref[r][3])       # the solve: objective and x
+        assert out[r][4] == ref[r][4] and out[r][5] == ref[r][5] and out[r][8] == ref[r][8]   # ECP iterations, cuts, PDHG iterations
+        assert out[r][9][1] <= 1e-12                                                 # the probe: sum and max as every rank computes them itself
+    assert out[0][2] == out[1][2] and np.array_equal(out[0][3], out[1][3])
+    assert abs(out[0][2] - inst.opt_obj) <= planted_obj_bound(inst)
+    assert max_nl_violation(inst, out[0][3]) <= 1e-6 * (1 + 1e-6)
+
+
+@pytest.mark.gpu
+def test_three_rank_row_sharded_solve_over_the_peer_buffer_transport():
+    """three processes on cuda:0: more than one peer per rank (the flag words per source, the alternating slots); every rank ends
+    with the same x, bit for bit, at the planted optimum"""
+    import katana_jl_amd as ktn
+    from helpers import max_nl_violation, planted_obj_bound
+    world = 3
+    inst_kw = dict(n=3000, m_nl=300, k=16, family="explog", seed=2)
+    out = mp.Manager().dict()
+    mp.spawn(_worker_rowshard_gpu, args=(world, _free_port(), out, inst_kw, False, "ipc"), nprocs=world, join=True)
+    inst = ktn.instances.make_instance(**inst_kw)
+    for r in range(world):
+        assert out[r][0][0] == "Optimal" and out[r][0][4] == "ipc" and out[r][1] == "Optimal"
+        assert out[r][2] == out[0][2] and np.array_equal(out[r][3], out[0][3]) and out[r][4] == out[0][4]
+        assert out[r][9][1] <= 1e-12
+    assert abs(out[0][2] - inst.opt_obj) <= planted_obj_bound(inst)
+    assert max_nl_violation(inst, out[0][3]) <= 1e-6 * (1 + 1e-6)
+
+
+def _worker_ipc_absent_peer(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["KTN_IPC_TIMEOUT_S"] = "1"
+    import torch.distributed as dist
+    import katana_jl_amd as ktn
+    from katana_jl_amd.distributed import RowShardedKatanaModel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    inst = ktn.instances.make_instance(n=200, m_nl=20, k=8, family="explog", seed=1)
+    m = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0), inst, rank, world, dist, transport="ipc")
+    t0 = time.time()
+    if rank == 0:                               # rank 1 never enters this collective
+        try:
+            m.allreduce_probe(100, 1)
+            out[0] = ("no error", time.time() - t0)
+        except Exception as e:
+            out[0] = (str(e), time.time() - t0)
+    dist.barrier()
+    del m
+    out[10 + rank] = time.time() - t0
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_peer_buffer_transport_times_out_instead_of_hanging():
+    """every spin of the transport is bounded: a rank whose peer never arrives gets an error naming that peer after
+    KTN_IPC_TIMEOUT_S, and both processes still shut down"""
+    out = mp.Manager().dict()
+    mp.spawn(_worker_ipc_absent_peer, args=(2, _free_port(), out), nprocs=2, join=True)
+    msg, secs = out[0]
+    assert "timed out waiting for rank 1" in msg and 0.9 <= secs < 10.0
+    assert out[10] < 15.0 and out[11] < 15.0
 
 
 def _worker_rowshard_few_nl(rank, world, port, out, inst_kw):
