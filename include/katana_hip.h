@@ -309,6 +309,11 @@ double ktn_get_stat(ktn_handle h, const char* name);
  *   ktn_lp_append_rows   : append a CSR block of rows (rowptr 0-based), duals start at 0
  * Use lp_dual_inherit = 0 with truncate/append (row indices of earlier cuts change). */
 int ktn_sweep_lp_point(ktn_handle h, double f_tol, int64_t* nviol, double* maxviol);
+/* this handle's share of the objective certificate (sum over ITS NL rows of multiplier mass x signed residual at the last sweep's
+ * point; the engine's own loop evaluates the same sum over all rows after the stop rule is met, src/model.jl:257 +
+ * test/runtests.jl:16-17): the host loop adds the shares of all ranks and clamps at zero.  id_offset = global id of the
+ * handle's first NL row (ktn_lp_enable_global_lists), 0 otherwise. */
+int ktn_objective_certificate(ktn_handle h, int64_t id_offset, double* sum);
 int64_t ktn_lp_nnz_from(ktn_handle h, int64_t first_row);
 int ktn_lp_get_rows_from(ktn_handle h, int64_t first_row, int64_t* rowptr, int32_t* col, double* val,
                          double* lo, double* hi);

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "ktn_get_lp_sol": (c_i32, [C.c_void_p, c_i64, P(c_f64), c_i64]),
     "ktn_get_stat": (c_f64, [C.c_void_p, C.c_char_p]),
     "ktn_sweep_lp_point": (c_i32, [C.c_void_p, c_f64, P(c_i64), P(c_f64)]),
+    "ktn_objective_certificate": (c_i32, [C.c_void_p, c_i64, P(c_f64)]),
     "ktn_lp_nnz_from": (c_i64, [C.c_void_p, c_i64]),
     "ktn_lp_get_rows_from": (c_i32, [C.c_void_p, c_i64, P(c_i64), P(c_i32), P(c_f64), P(c_f64), P(c_f64)]),
     "ktn_lp_truncate": (c_i32, [C.c_void_p, c_i64]),

@@ -359,7 +359,7 @@ struct Engine {
     double polish_phi = 1e-3;       // the refinement cuts rows beyond polish_phi * f_tol
     double cert_target = 0.0;       // > 0: certificate-driven refinement (kernels.hpp "objective certificate"), ends when met
     DBuf<double> d_cert;
-    double objective_certificate();
+    double objective_certificate(int64_t id_offset = 0, bool raw = false);
     double best_viol = kInf, best_obj = 0.0;
     DBuf<double> d_xbest;
     // print_header / print_stats bookkeeping  src/model.jl:209-217,252-254,284-303
@@ -2787,16 +2787,19 @@ void Engine::polish_step(int32_t* done) {
 }
 
 // max(sum_i lambda_i res_i, 0) over the NL rows at (lp_x, lp_y), with g of the last sweep (kernels.hpp "objective certificate")
-double Engine::objective_certificate() {
+// (id_offset: the global id of this handle's first NL row when the cut lists are global -- NL-row blocks over several GPUs;
+//  raw: the signed sum, for the caller to add up over the ranks before clamping)
+double Engine::objective_certificate(int64_t id_offset, bool raw) {
     if (m_nl <= 0) return 0.0;
     d_cert.resize((size_t)m_nl, stream);
-    LAUNCH_1(k_cert_nl, m_nl, stream, m_nl, d_nlrows.p, list_heads(), d_cutprev.p, lp_y.p, d_g.p, d_lb.p, d_ub.p, prm.f_tol, d_cert.p);
+    LAUNCH_1(k_cert_nl, m_nl, stream, m_nl, d_nlrows.p, list_heads() + id_offset, d_cutprev.p, lp_y.p, d_g.p, d_lb.p, d_ub.p, prm.f_tol, d_cert.p);
     hipLaunchKernelGGL(k_sum_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, m_nl, d_cert.p, partials.p);
     hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, d_scal.p);
     check_launch();
     double D = 0.0;
     KTN_HIP(hipMemcpyAsync(&D, d_scal.p, sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
+    if (raw) return D;
     return (D == D) ? std::max(D, 0.0) : kInf;
 }
 
@@ -3103,6 +3106,19 @@ int ktn_sweep_lp_point(ktn_handle h, double f_tol, int64_t* nviol, double* maxvi
         if (nviol) *nviol = nv;
         if (maxviol) *maxviol = mv;
         if (nf) e->status = KTN_STATUS_ERROR;
+        return KTN_OK;
+    })
+}
+// sum over this handle's NL rows of (multiplier mass of the row's cuts) x (signed residual at the last sweep's point): the
+// handle's share of the objective certificate (kernels.hpp "objective certificate") when the NL rows are split over several
+// handles -- the caller adds the shares and clamps at zero.  id_offset: global id of the handle's first NL row (global lists).
+int ktn_objective_certificate(ktn_handle h, int64_t id_offset, double* sum) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && sum && id_offset >= 0, "objective_certificate: bad arguments");
+        KTN_REQUIRE(e->lists_ok() && (e->glists ? id_offset + e->m_nl <= e->list_count() : id_offset == 0),
+                    "objective_certificate: no cut lists for these rows (ktn_lp_enable_global_lists)");
+        *sum = e->objective_certificate(id_offset, true);
         return KTN_OK;
     })
 }

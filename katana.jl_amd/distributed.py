@@ -181,6 +181,10 @@ class ShardedKatanaModel:
         self.iter, self.allsat, self._status, self.last_maxviol = 0, False, "None", 1e300
         self.exchanged_rows = 0
         self.purged_rows = 0
+        # terminal refinement (Engine::step / polish_step, mirrored): state, the best point so far, the answer once finished
+        self._refining, self._refined, self._phi, self._cert_target, self._pcount = False, False, 1.0, 0.0, 0
+        self._best, self._final = None, None
+        self.cert_refinements, self.polish_iters = 0, 0
 
     def reset(self):
         self.m.reset()
@@ -189,24 +193,18 @@ class ShardedKatanaModel:
     def optimize_begin(self):
         self.m.optimize_begin()          # box-bounded shards: no presolve work, starts the solve timer
 
-    def ecp_step(self):
-        """one pass of src/model.jl:258-308 across all ranks; returns True when the loop ends"""
-        if self.allsat or self.iter >= self.p["iter_cap"] or self._status in ("Error", "Unbounded"):
-            return True
-        self.iter += 1
-        f_tol = self.p["f_tol"]
-        floor_p = self.tol["floor"] * f_tol
-        tol_p = min(max(self.tol["scale"] * self.last_maxviol, floor_p), self.tol["cap"])
-        tol_g = min(max(tol_p, self.tol["gfloor"]), self.tol["gcap"])
-        lp_status, _ = self.m.lp_solve(tol_p, tol_g)
-        lp_ok = lp_status == "Optimal"
+    def _sweep_and_exchange(self, f_cut, lp_ok=True, lp_status="Optimal", purge=False):
+        """every rank sweeps its block of NL rows at the LP point (rows beyond f_cut get a cut), the cuts of all ranks are
+        appended in rank order.  Returns (cuts appended, largest violation, leave): `leave` = some rank's LP or sweep failed and
+        the status is set -- every rank sees the same flags and leaves in the same iteration."""
         m0 = self.m.lp_num_rows()
         device_resident = self.exchange_device == "cuda" and self.dist is not None and self.world > 1
         block = None
         if lp_ok:
-            self.purged_rows += self.m.lp_purge()                 # identical LPs => identical purge on every rank
-            m0 = self.m.lp_num_rows()
-            nv_local, mv_local = self.m.sweep_lp_point(f_tol)
+            if purge:
+                self.purged_rows += self.m.lp_purge()             # identical LPs => identical purge on every rank
+                m0 = self.m.lp_num_rows()
+            nv_local, mv_local = self.m.sweep_lp_point(f_cut)
             err_local = self.m.status() == "Error"
             if not device_resident:
                 block = tuple(self.m.lp_rows_from(m0)) + (self.shard_lo + self.m.last_sweep_slots(),)
@@ -222,12 +220,12 @@ class ShardedKatanaModel:
             nviol, maxviol, flags = exchange_cuts_dev(self.dist, self.m, m0, self.shard_lo, (mv_local, flag))
             if flags >= 2.0:
                 self._status = lp_status if not lp_ok else "Error"
-                return True
+                return 0, maxviol, True
         else:
             blocks, maxviol, flags = exchange_cuts(self.dist, block, self.exchange_device, scalars=(mv_local, flag))
             if flags >= 2.0:
                 self._status = lp_status if not lp_ok else "Error"
-                return True
+                return 0, maxviol, True
             nviol = 0
             for rp, col, val, lo, hi, ids in blocks:             # rank order => identical LP everywhere
                 self.m.lp_append_rows(rp, col, val, lo, hi, ids)
@@ -235,6 +233,33 @@ class ShardedKatanaModel:
         self.exchanged_rows += nviol
         if flags >= 1.0:
             self._status = "Error"
+            return nviol, maxviol, True
+        return nviol, maxviol, False
+
+    def _certificate(self):
+        """sum over ALL NL rows of multiplier mass x signed residual (every rank adds its block; one tiny all-reduce), clamped"""
+        d = self.m.objective_certificate(self.shard_lo)
+        if self.dist is not None and self.world > 1:
+            import torch
+            t = torch.tensor([d], dtype=torch.float64, device="cuda" if self.dist.get_backend() == "nccl" else "cpu")
+            self.dist.all_reduce(t)
+            d = float(t.item())
+        return max(d, 0.0) if d == d else float("inf")
+
+    def ecp_step(self):
+        """one pass of src/model.jl:258-308 across all ranks; returns True when the loop ends"""
+        if self._refining:
+            return self._refine_step()
+        if self.allsat or self.iter >= self.p["iter_cap"] or self._status in ("Error", "Unbounded"):
+            return True
+        self.iter += 1
+        f_tol = self.p["f_tol"]
+        floor_p = self.tol["floor"] * f_tol
+        tol_p = min(max(self.tol["scale"] * self.last_maxviol, floor_p), self.tol["cap"])
+        tol_g = min(max(tol_p, self.tol["gfloor"]), self.tol["gcap"])
+        lp_status, _ = self.m.lp_solve(tol_p, tol_g)
+        nviol, maxviol, leave = self._sweep_and_exchange(f_tol, lp_status == "Optimal", lp_status, purge=True)
+        if leave:
             return True
         self.last_maxviol = maxviol
         # Engine::step's floor rule: satisfied at a loosely solved LP only counts when that solve already meets the floor
@@ -248,7 +273,71 @@ class ShardedKatanaModel:
             self.last_maxviol = 0.0                                # satisfied at a loosely solved LP: tighten first
         else:
             self.allsat = nviol == 0
+        # Terminal refinement, as Engine::step decides it: fixed factor for the reference's own small models, the objective
+        # certificate beyond (identical LPs and an all-reduced certificate: every rank takes the same decision)
+        prm = self.m.params
+        if self.allsat and not self._refined and self.iter < self.p["iter_cap"] and prm.polish_max_iter > 0 and self.inst.m_nl > 0:
+            if self.m.num_var <= prm.polish_max_var:
+                if 0.0 < prm.polish_factor < 1.0:
+                    self._refining, self._phi, self._cert_target = True, prm.polish_factor, 0.0
+            elif prm.obj_cert_tol > 0.0:
+                target = prm.obj_cert_tol * max(1.0, abs(self.m.getobjval()))
+                d = self._certificate()
+                if d > 0.5 * target:
+                    self._refining, self._cert_target = True, target
+                    self._phi = min(max(0.25 * target / d, 0.05), 0.5)
+                    self.cert_refinements += 1
+            if self._refining:
+                self._pcount, self._best = 0, None
+                return False
         return self.allsat or self.iter >= self.p["iter_cap"]
+
+    def _consider(self, viol):
+        if viol <= self.p["f_tol"] and (self._best is None or viol < self._best[0]):
+            self._best = (viol, self.m.getobjval(), self.m.getsolution())
+
+    def _finish_refinement(self):
+        self._refining, self._refined = False, True
+        if self._best is not None:
+            self._final = self._best[1:]
+        return True
+
+    def _refine_step(self):
+        """Engine::polish_step across the ranks: LP at the refinement tolerance, cuts for every row beyond phi * f_tol; the answer
+        is the point with the smallest violation among those that satisfy the reference's stop rule"""
+        prm, f_tol = self.m.params, self.p["f_tol"]
+        f_eff = self._phi * f_tol
+        if self._pcount == 0:                    # first pass: measure (and cut at) the point that met the stop rule
+            nviol, mv, leave = self._sweep_and_exchange(f_eff)
+            if leave:
+                return True
+            self._consider(mv)
+            self._pcount = 1
+            if nviol == 0 and self._cert_target <= 0.0:
+                return self._finish_refinement()
+            return False
+        if self._pcount > prm.polish_max_iter:
+            return self._finish_refinement()
+        self._pcount += 1
+        self.polish_iters += 1
+        tol_p = self.tol["floor"] * f_eff
+        if self._cert_target > 0.0:
+            tol_g = min(min(max(tol_p, self.tol["gfloor"]), self.tol["gcap"]),
+                        0.25 * self._cert_target / (1.0 + 2.0 * abs(self.m.getobjval())))
+        else:
+            tol_g = max(self.tol["gfloor"] * self._phi, 1e-12)
+        lp_status, _ = self.m.lp_solve(tol_p, tol_g)
+        if lp_status != "Optimal":               # (identical LPs: the same on every rank) keep the point that met the stop rule
+            return self._finish_refinement()
+        nviol, mv, leave = self._sweep_and_exchange(f_eff)
+        if leave:
+            return self._finish_refinement()
+        self._consider(mv)
+        if self._cert_target > 0.0 and mv <= f_tol and self._certificate() <= 0.5 * self._cert_target:
+            return self._finish_refinement()
+        if nviol == 0:
+            return self._finish_refinement()
+        return False
 
     def optimize_end(self):
         self.m.optimize_end()
@@ -265,13 +354,14 @@ class ShardedKatanaModel:
 
     # getters of the plugin surface
     def status(self): return self._status
-    def getobjval(self): return self.m.getobjval()
-    def getsolution(self): return self.m.getsolution()
+    def getobjval(self): return self._final[0] if self._final is not None else self.m.getobjval()
+    def getsolution(self): return self._final[1] if self._final is not None else self.m.getsolution()
     def getsolvetime(self): return self.m.getsolvetime()
     def numiters(self): return self.iter
     def numcuts(self): return self.m.numcuts()
     def lp_num_rows(self): return self.m.lp_num_rows()
-    def stat(self, name): return self.m.stat(name)
+    def stat(self, name):
+        return float(getattr(self, name)) if name in ("cert_refinements", "polish_iters") else self.m.stat(name)
 
 
 # =====================================================================================================================

@@ -184,6 +184,13 @@ class KatanaNonlinearModel:
         L.check(self._h, self._lib.ktn_sweep_lp_point(self._h, f_tol, C.byref(nv), C.byref(mv)))
         return int(nv.value), float(mv.value)
 
+    def objective_certificate(self, id_offset=0):
+        """this handle's share of sum_i lambda_i * (signed residual of NL row i) at the last sweep's point (signed; the caller
+        adds the shares of all handles and clamps at zero)"""
+        v = C.c_double(0.0)
+        L.check(self._h, self._lib.ktn_objective_certificate(self._h, int(id_offset), C.byref(v)))
+        return float(v.value)
+
     def lp_rows_from(self, first_row):
         nr = self.lp_num_rows() - first_row
         nz = int(self._lib.ktn_lp_nnz_from(self._h, first_row))

@@ -180,6 +180,41 @@ def test_two_rank_sharded_solve_with_the_device_resident_cut_exchange():
     assert single.optimize() == "Optimal"
 
 
+def _worker_gpu_cert(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import katana_jl_amd as ktn
+    from katana_jl_amd.distributed import ShardedKatanaModel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    inst = ktn.instances.make_config("cfg3", seed=6)
+    m = ShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0), inst, rank, world, dist, exchange_device="cuda")
+    st = m.optimize()
+    out[rank] = (st, m.getobjval(), m.numiters(), m.stat("cert_refinements"), m.stat("polish_iters"), m.getsolution())
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_solve_refines_by_the_objective_certificate():
+    """cfg3 seed 6 meets the stop rule 1.5e-6 (relative) away from the optimum; the engine's own loop then keeps cutting below
+    f_tol until the objective certificate -- sum over the NL rows of multiplier mass x residual -- is within half the
+    reference's objective tolerance.  With the NL rows split over two ranks every rank contributes its block's share
+    (ktn_objective_certificate) and the host loop takes the same decision: one refinement, the objective within 1e-6 / 1e-6 of
+    the planted one, the single-GPU trajectory bit for bit."""
+    import katana_jl_amd as ktn
+    from helpers import assert_planted_objective, hip_load_instance
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker_gpu_cert, args=(world, _free_port(), out), nprocs=world, join=True)
+    inst = ktn.instances.make_config("cfg3", seed=6)
+    single = hip_load_instance(ktn, inst)
+    assert single.optimize() == "Optimal" and single.stat("cert_refinements") == 1
+    for r in range(world):
+        st, obj, iters, refinements, polish, x = out[r]
+        assert st == "Optimal" and refinements == 1 and polish == single.stat("polish_iters")
+        assert obj == single.getobjval() and iters == single.numiters() and np.array_equal(x, single.getsolution())
+    assert_planted_objective(out[0][1], inst)
+
+
 @pytest.mark.gpu
 def test_sharded_model_world1_equals_engine_loop():
     import katana_jl_amd as ktn
