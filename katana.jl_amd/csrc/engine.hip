@@ -300,6 +300,14 @@ struct Engine {
     DBuf<int32_t> ds_W, ds_valid;
     DBuf<double> ds_dense, ds_out;
     DBuf<int32_t> d_longrows;
+    // long COLUMNS of the mirror (a variable that every cut contains: min-max / epigraph-style models): found by find_long_cols
+    // after the mirror is built; the column-side kernels then run in their vector form with a workgroup per long column
+    DBuf<int32_t> d_longcols;
+    int64_t n_longc = 0;
+    int64_t col_gain_max = 0;                      // most NL rows sharing one column: what a column can gain per sweep
+    int64_t col_len_max = -1, col_scan_rows = 0;   // longest column at the last scan, rows of the LP then (-1: never scanned)
+    void find_long_cols();
+    void spmv_cols(const SpMat& AT, const double* v, double* out, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
     static constexpr int kMaxChunk = 512;
     int64_t n_long = 0;
     static constexpr int64_t kLongRow = 2048;
@@ -411,7 +419,7 @@ struct Engine {
             (void)hipGetLastError();
         }
         d_scal.resize(8, stream);
-        d_anynf.resize(2, stream);
+        d_anynf.resize(4, stream);
     }
     ~Engine() {
         if (dist.comm) (void)ncclCommDestroy(dist.comm);
@@ -1030,6 +1038,15 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     max_row_len = 2;                                   // (the bound-box vertex row and other engine-made rows are short)
     for (size_t i = 0; i + 1 < h_rowptr.size(); ++i) max_row_len = std::max(max_row_len, h_rowptr[i + 1] - h_rowptr[i]);
     {
+        // a cut has the sparsity of its NL row: the most entries ONE column can gain per sweep is the number of NL rows that
+        // contain it (1-2 on the BASELINE shapes; m_nl for a variable every row shares -- min-max / epigraph-style models)
+        std::vector<int32_t> cnt((size_t)n_lp + 1, 0);
+        col_gain_max = 0;
+        for (int32_t i : h_nlrows)
+            for (int64_t e = h_rowptr[(size_t)i]; e < h_rowptr[(size_t)i + 1]; ++e)
+                col_gain_max = std::max<int64_t>(col_gain_max, ++cnt[(size_t)h_col[(size_t)e]]);
+    }
+    {
         // packed row programs: the three arrays go up as they are and are packed on the device (k_pack_atoms)
         uint8_t kmax = 0;
         for (size_t e = 0; e < akind.size(); ++e) kmax = std::max(kmax, akind[e]);
@@ -1310,7 +1327,7 @@ void Engine::reset() {
     d_lastcut.upload(neg1, stream);
     d_age.resize((size_t)std::max<int64_t>(M, 1), stream);
     d_age.zero(stream);
-    lp_dirty = true; ++lp_version; ++lp_epoch; have_omega = false; have_precompute = false; sharded_rows = false; scal_rows = 0; smax_rows = 0;
+    lp_dirty = true; ++lp_version; ++lp_epoch; have_omega = false; have_precompute = false; sharded_rows = false; scal_rows = 0; smax_rows = 0; n_longc = 0; col_len_max = -1; col_scan_rows = 0;
     blocks_built_rows = -1;
     if (d_blkomega.n) d_blkomega.zero(stream);
     if (ds_valid.n) ds_valid.zero(stream);
@@ -1333,7 +1350,10 @@ void Engine::reset() {
 void Engine::rebuild_csc() {
     const bool no_merge = std::getenv("KTN_NO_CSC_MERGE") != nullptr;       // (tests: the sort path for every solve)
     c_val.resize((size_t)NNZ + 1, stream);
-    if (!no_merge && csc_epoch == lp_epoch && csc_M >= 0 && M >= csc_M && NNZ >= csc_NNZ && NNZ < ((int64_t)1 << 32)) {
+    // (long columns: the merge orders a column's new entries by insertion -- fine for the 0.3 entries a column gains per sweep,
+    //  quadratic for a column that gains one per cut; the radix sort does not care)
+    const bool few_per_col = col_gain_max <= (sharded_rows ? 8 : 64);      // (host-appended rows: other ranks' cuts come on top)
+    if (!no_merge && n_longc == 0 && few_per_col && csc_epoch == lp_epoch && csc_M >= 0 && M >= csc_M && NNZ >= csc_NNZ && NNZ < ((int64_t)1 << 32)) {
         if (M > csc_M) csc_merge_appended();              // (M == csc_M: same structure, only the values are gathered again)
         stats["lp_csc_merges"] += 1.0;
     } else {
@@ -1368,6 +1388,46 @@ void Engine::rebuild_csc() {
     csc_epoch = lp_epoch; csc_M = M; csc_NNZ = NNZ;
     lp_dirty = false;
     blocks_built_rows = -1;
+    find_long_cols();
+}
+// Columns longer than kLongRow.  A column gains at most one entry per appended row, so between scans the longest possible
+// column is known on the host: no scan (and no round trip) while that bound stays below the threshold.
+void Engine::find_long_cols() {
+    if (col_len_max >= 0 && M >= col_scan_rows && n_longc == 0 && col_len_max + (M - col_scan_rows) <= kLongRow) return;
+    n_longc = 0;
+    if (M <= kLongRow || n_blocks > 0) { col_len_max = std::min<int64_t>(M, kLongRow); col_scan_rows = M; return; }
+    d_longcols.resize((size_t)n_lp, stream);
+    KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, 2 * sizeof(int32_t), stream));
+    LAUNCH_1(k_find_long_max, n_lp, stream, n_lp, c_ptr.p, kLongRow, d_longcols.p, d_anynf.p + 1);
+    int32_t r[2] = {0, 0};
+    KTN_HIP(hipMemcpyAsync(r, d_anynf.p + 1, 8, hipMemcpyDeviceToHost, stream));
+    sync();
+    n_longc = r[0];
+    col_len_max = r[1];
+    col_scan_rows = M;
+    stats["lp_long_col_scans"] += 1.0;
+    stats["lp_long_cols"] = (double)n_longc;
+    stats["lp_long_cols_max"] = std::max(stats["lp_long_cols_max"], (double)n_longc);
+    if (n_longc > 1) {                                  // list order = order of the workgroups' sums: make it reproducible
+        std::vector<int32_t> tmp((size_t)n_longc);
+        KTN_HIP(hipMemcpyAsync(tmp.data(), d_longcols.p, (size_t)n_longc * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        sync();
+        std::sort(tmp.begin(), tmp.end());
+        KTN_HIP(hipMemcpyAsync(d_longcols.p, tmp.data(), (size_t)n_longc * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        sync();
+    }
+}
+// out = A'v over the mirror: G lanes per column, a 1024-thread workgroup per long column
+void Engine::spmv_cols(const SpMat& AT, const double* v, double* out, hipEvent_t e0, hipEvent_t e1) {
+    const int64_t n = n_lp;
+    if (n_longc > 0) {
+        LAUNCH_G(grp_cols, k_spmv_skip, n, stream, n, AT, v, out, kLongRow);
+        hipLaunchKernelGGL(k_spmv_long, dim3((unsigned)n_longc), dim3(1024), 0, stream, d_longcols.p, AT, v, out);
+    } else if (e0) {
+        LAUNCH_G_EV(grp_cols, k_spmv, n, stream, e0, e1, n, AT, v, out);
+    } else {
+        LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, v, out);
+    }
 }
 // rows [csc_M, M) were appended since the mirror was built (kernels.hpp "append-only update of the mirror")
 void Engine::csc_merge_appended() {
@@ -1534,7 +1594,7 @@ void Engine::compute_scaling(bool identity) {
                 KTN_HIP(hipMemcpyAsync(dr_r.p, dr.p, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, stream));
                 KTN_HIP(hipMemcpyAsync(dc_r.p, dc.p, (size_t)n_lp * sizeof(double), hipMemcpyDeviceToDevice, stream));
             }
-            if (n_long == 0 && !row_sharded() && M > 0) {
+            if (n_long == 0 && n_longc == 0 && !row_sharded() && M > 0) {
                 // statistic + update in one launch per side, into new arrays that are swapped in (22 launches instead of 33)
                 dr2.resize((size_t)M, stream); dc2.resize((size_t)n_lp, stream);
                 LAUNCH_G(gr, k_scale_stat_upd, M, stream, M, lp_rowptr.p, lp_col.p, Wval(), dr.p, dc.p, mode, dr2.p, kInf);
@@ -1549,7 +1609,13 @@ void Engine::compute_scaling(bool identity) {
             } else {
                 LAUNCH_G(gr, k_scale_stat, M, stream, M, lp_rowptr.p, lp_col.p, Wval(), dr.p, dc.p, mode, statr.p);
             }
-            LAUNCH_G(gc, k_scale_stat, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, statc.p);
+            if (n_longc > 0) {
+                LAUNCH_G(gc, k_scale_stat_skip, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, statc.p, kLongRow);
+                hipLaunchKernelGGL(k_scale_stat_long, dim3((unsigned)n_longc), dim3(1024), 0, stream, d_longcols.p, c_ptr.p, c_row.p,
+                                   c_val.p, dc.p, dr.p, mode, statc.p);
+            } else {
+                LAUNCH_G(gc, k_scale_stat, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, statc.p);
+            }
             if (row_sharded()) {                       // a column's max / sum runs over the rows of every rank
                 if (M == 0) LAUNCH_1(k_fill, n_lp, stream, n_lp, statc.p, 0.0);
                 allreduce(statc.p, (size_t)n_lp, mode ? 0 : 1);
@@ -1562,7 +1628,9 @@ void Engine::compute_scaling(bool identity) {
     r_sval.resize((size_t)NNZ + 1, stream);
     c_sval.resize((size_t)NNZ + 1, stream);
     LAUNCH_G(gr, k_scale_vals, M, stream, M, lp_rowptr.p, lp_col.p, Wval(), dr.p, dc.p, r_sval.p);
-    LAUNCH_G(gc, k_scale_vals, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, c_sval.p);
+    // (long columns: the mirror's scaled values are gathered entry-parallel from the row copy instead of walked column by column)
+    if (n_longc > 0) LAUNCH_1(k_csc_vals, NNZ, stream, NNZ, c_perm.p, r_sval.p, c_sval.p);
+    else LAUNCH_G(gc, k_scale_vals, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, c_sval.p);
     check_launch();
 }
 
@@ -1873,8 +1941,7 @@ void Engine::launch_x(const SpMat& AT, double tau, double w, double rho, bool up
             launch_tiled(tAT, n, M, yh.p, e0);
             hipExtLaunchKernelGGL(k_tile_vec, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, stream, nullptr, e1, 0, n, tAT.pcnt.p, tpart.p, part);
         }
-        else if (e0) LAUNCH_G_EV(grp_cols, k_spmv, n, stream, e0, e1, n, AT, yh.p, part);
-        else LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, yh.p, part);
+        else spmv_cols(AT, yh.p, part, e0, e1);
         if (ipc) {
             stats["allreduce_calls"] += 1.0;
             stats["allreduce_bytes"] += 8.0 * (double)n;
@@ -1884,6 +1951,13 @@ void Engine::launch_x(const SpMat& AT, double tau, double w, double rho, bool up
             return;
         }
         allreduce(pv.p, (size_t)n, 0);
+        if (update) LAUNCH_1(k_x_prox<true>, n, stream, n, pv.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        else LAUNCH_1(k_x_prox<false>, n, stream, n, pv.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        return;
+    }
+    if (n_longc > 0 && !(tiled_on && M > 0)) {
+        // long columns: A'y as a vector (lane groups + a workgroup per long column), then the element-wise primal step
+        spmv_cols(AT, yh.p, pv.p, e0, e1);
         if (update) LAUNCH_1(k_x_prox<true>, n, stream, n, pv.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
         else LAUNCH_1(k_x_prox<false>, n, stream, n, pv.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
         return;
@@ -1958,9 +2032,9 @@ void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double si
                                yh.p, y0h.p, yth.p, loh.p, hih.p, dr.p, sigma, 0.0, 1.0, prow + (size_t)brow * kChkQ);
     }
     chk_nrow = (m > 0) ? (int)(brow + n_long) : 0;
-    if (row_sharded()) {
+    if (row_sharded() || n_longc > 0) {
         if (m == 0) LAUNCH_1(k_fill, n, stream, n, pv.p, 0.0);
-        LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, yth.p, pv.p);
+        spmv_cols(AT, yth.p, pv.p);
         allreduce(pv.p, (size_t)n, 0);
         chk_ncol = ceil_div(n, kBlock);             // <= bcol: the column partials fit the same region
         LAUNCH_1(k_chk_cols_vec, n, stream, n, pv.p, xh.p, xth.p, x0h.p, ch.p, lh.p, uh.p, dc.p, pcol);
@@ -2171,12 +2245,12 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             }
             const bool norm_now = (it % 4 == 3) || it >= iters - 2;
             if (norm_now) {
-                LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, pw.p, xbar.p);
+                spmv_cols(AT, pw.p, xbar.p);
                 allreduce(xbar.p, (size_t)n, 0);            // row-sharded: A'A v = sum over the ranks of A_r'(A_r v)
                 dot_dev(xbar.p, nrm);                       // on the last pass: ||A'A v||^2 with ||v|| = 1
                 LAUNCH_1(k_normalize, n, stream, n, xbar.p, nrm, pv.p);
             } else {
-                LAUNCH_G(grp_cols, k_spmv, n, stream, n, AT, pw.p, pv.p);
+                spmv_cols(AT, pw.p, pv.p);
                 allreduce(pv.p, (size_t)n, 0);
             }
         }
@@ -2514,8 +2588,8 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
     const int64_t n = n_lp, m = M;
     const size_t mm = (size_t)std::max<int64_t>(m, 1);
     ch.resize(n, stream); lh.resize(n, stream); uh.resize(n, stream); xh.resize(n, stream);
-    x0h.resize(n, stream); xth.resize(n, stream); xbar.resize(n, stream);
-    loh.resize(mm, stream); hih.resize(mm, stream); yh.resize(mm, stream); y0h.resize(mm, stream); yth.resize(mm, stream);
+    x0h.resize(n, stream); xth.resize(n, stream); xbar.resize(n, stream); pv.resize(n, stream);      // (pv: vector form of the x-step)
+    loh.resize(mm, stream); hih.resize(mm, stream); yh.resize(mm, stream); y0h.resize(mm, stream); yth.resize(mm, stream); pw.resize(mm, stream);
     const double sgn = (sense == KTN_MAX) ? -1.0 : 1.0;
     KTN_HIP(hipMemcpyAsync(lp_x.p, x0, n * sizeof(double), hipMemcpyHostToDevice, stream));
     if (m > 0) KTN_HIP(hipMemcpyAsync(lp_y.p, y0, m * sizeof(double), hipMemcpyHostToDevice, stream));

@@ -1181,6 +1181,23 @@ __global__ __launch_bounds__(kBlock) void k_find_long(int64_t m, const int64_t* 
     if (rowptr[i + 1] - rowptr[i] > thresh) list[atomicAdd(count, 1)] = (int32_t)i;
 }
 
+// the same for the columns of the mirror, with the longest length reported too (count[0]: long ones, count[1]: max length)
+__global__ __launch_bounds__(kBlock) void k_find_long_max(int64_t n, const int64_t* __restrict__ ptr, int64_t thresh,
+                                                          int32_t* __restrict__ list, int32_t* __restrict__ count) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int len = 0;
+    if (j < n) {
+        len = (int)(ptr[j + 1] - ptr[j]);
+        if (len > thresh) list[atomicAdd(count, 1)] = (int32_t)j;
+    }
+    __shared__ int s_max;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    if (len > 0) atomicMax(&s_max, len);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max > 0) atomicMax(count + 1, s_max);
+}
+
 // Restart: z <- T(z), anchor z0 <- T(z), primal and dual part in one launch (instead of four device-to-device copies);
 // the packed records of the plain steps carry x0 / y0 too.
 __global__ __launch_bounds__(kBlock) void k_restart_set(int64_t n, int64_t m, const double* __restrict__ xt, double* __restrict__ x,

@@ -106,7 +106,13 @@ def atom_value_deriv(kind, p0, p1, xv):
 
 def make_instance(n, m_nl, k, family="explog", seed=0, m_lin=None, lin_nnz=8, B=10.0,
                   active_frac=0.05, objective="linear", vertex=True, lin_active_frac=0.3,
-                  pivot_boost=True):
+                  pivot_boost=True, shared_column=False):
+    """`shared_column` (or a family name ending in "+t"): one more variable t that EVERY nonlinear row contains,
+    g_i(x) - t <= r_i - that (the shape of min-max and epigraph models: minimise t subject to g_i(x) <= t).  Every cut then
+    has an entry in t's column, which grows by up to m_nl entries per sweep -- the LP's long-column case.  t sits on its
+    lower bound that with multiplier 1 and cost sum(lambda) + 1, so the planted point stays a non-degenerate KKT vertex."""
+    if family.endswith("+t"):
+        family, shared_column = family[:-2], True
     rng = np.random.default_rng(seed)
     m_lin = n // 2 if m_lin is None else m_lin
     lin_nnz = min(lin_nnz, n)
@@ -218,6 +224,22 @@ def make_instance(n, m_nl, k, family="explog", seed=0, m_lin=None, lin_nnz=8, B=
     else:
         raise ValueError(objective)
 
+    if shared_column:
+        if objective != "linear":
+            raise ValueError("shared_column needs the linear objective")
+        that = 0.25
+        ncol = np.concatenate([ncol2, np.full((m_nl, 1), n)], axis=1).reshape(-1)
+        nkind = np.concatenate([nkind.reshape(m_nl, k), np.full((m_nl, 1), ATOM_LIN, dtype=np.uint8)], axis=1).reshape(-1)
+        np0 = np.concatenate([np0.reshape(m_nl, k), np.full((m_nl, 1), -1.0)], axis=1).reshape(-1)
+        np1 = np.concatenate([np1.reshape(m_nl, k), np.zeros((m_nl, 1))], axis=1).reshape(-1)
+        r = r - that                                   # g_i(xhat) - that - r' = -slack_i
+        ct = float(lam.sum()) + 1.0
+        obj_col, obj_kind = np.append(obj_col, n), np.append(obj_kind, np.uint8(ATOM_LIN))
+        obj_p0, obj_p1 = np.append(obj_p0, ct), np.append(obj_p1, 0.0)
+        opt += ct * that
+        xhat = np.append(xhat, that)
+        l_var, u_var = np.append(l_var, that), np.append(u_var, B)
+        n, k = n + 1, k + 1
     rowptr = np.concatenate([np.arange(m_lin + 1) * lin_nnz,
                              m_lin * lin_nnz + np.arange(1, m_nl + 1) * k]).astype(np.int64)
     inst = SeparableInstance(
@@ -233,7 +255,7 @@ def make_instance(n, m_nl, k, family="explog", seed=0, m_lin=None, lin_nnz=8, B=
         xhat=xhat, opt_obj=opt, m_lin=m_lin, m_nl=m_nl,
         meta=dict(n=n, m_nl=m_nl, k=k, family=family, seed=seed, m_lin=m_lin, lin_nnz=lin_nnz, B=B,
                   active_frac=active_frac, objective=objective, n_active=int(active.sum()),
-                  vertex=bool(vertex), n_lin_active=int(lin_active.sum()),
+                  vertex=bool(vertex), n_lin_active=int(lin_active.sum()), shared_column=bool(shared_column),
                   # planted multipliers: an x with g_i(x) <= eps on the NL rows, a_r'x <= b_r + delta on the linear rows and the
                   # bounds met exactly has  c'x >= c'xhat - eps * lam_sum - delta * mu_sum  (Lagrangian bound at xhat)
                   lam_sum=float(lam.sum()), mu_sum=float(mu.sum())))

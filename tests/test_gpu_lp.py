@@ -79,6 +79,45 @@ def test_gpu_lp_matches_highs(seed):
     assert np.all(y[~np.isfinite(lo)] <= 1e-12)
 
 
+def test_long_column_lp_steps_match_numpy_and_the_solve_matches_highs():
+    """A variable that EVERY nonlinear row contains (min-max / epigraph-style models: g_i(x) - t <= r_i) gets an entry from every
+    cut: its column of the mirror is as long as the cut pool.  Beyond 2 048 entries the column side of the LP runs in its vector
+    form -- A'y by lane groups plus one 1 024-thread workgroup per long column, then the element-wise primal step -- the scaling
+    statistics and the power iteration likewise, and the mirror is rebuilt by the radix sort (the append-only merge orders a
+    column's new entries by insertion).  Raw iterations against the dense numpy recurrences to 1e-11, the solve against HiGHS."""
+    from oracle.lp import LinearModel
+    inst = ktn.instances.make_instance(n=300, m_nl=2600, k=6, family="explog+t", seed=4, m_lin=100)
+    m = hip_load_instance(ktn, inst, purge_age=0, cut_cap_factor=0.0)
+    sep = ktn.KatanaHipSeparator(m); sep.initialize()
+    x = np.clip(inst.xhat + 0.7, inst.l_var, inst.u_var)
+    x[-1] = -5.0                                                   # t far below: every row violated (a cut is valid wherever it is taken)
+    sep.precompute(x)
+    assert sep.sweep(1e-6)[0] > 2048
+    A, c, c0, lo, hi = _dense_lp(m)
+    assert np.count_nonzero(A[:, -1]) > 2048                       # the shared column
+    rng = np.random.default_rng(0)
+    x0 = rng.uniform(inst.l_var, inst.u_var)
+    y0 = rng.normal(size=len(lo)) * (np.isfinite(lo) | np.isfinite(hi))
+    y0 = np.where(np.isfinite(lo), y0, np.minimum(y0, 0.0))
+    eta, omega = 0.02, 1.3
+    xg, yg = m.lp_pdhg_raw(x0, y0, eta, omega, 20)
+    assert m.stat("lp_long_cols") == 1
+    xn, yn = _halpern_numpy(A, c, inst.l_var, inst.u_var, lo, hi, x0, y0, eta, omega, 20)
+    assert np.max(np.abs(xg - xn)) <= 1e-11 * (1 + np.max(np.abs(xn)))
+    assert np.max(np.abs(yg - yn)) <= 1e-11 * (1 + np.max(np.abs(yn)))
+    status, iters = m.lp_solve(row_tol=1e-8, gap_tol=1e-8)
+    assert status == "Optimal" and iters > 0 and m.stat("lp_long_cols") == 1
+    rowptr, col, val, lo, hi = m.lp_rows()
+    lm = LinearModel()
+    lm.add_variables(inst.l_var, inst.u_var)
+    lm.set_objective("Min", np.arange(inst.n), c, c0)
+    lm.add_rows(rowptr, col, val, lo, hi)
+    assert lm.solve() == "Optimal"
+    assert abs(m.getobjval() - lm.getobjval()) <= 1e-6 * max(1.0, abs(lm.getobjval()))
+    ax = A @ m.getsolution()
+    assert np.max(np.maximum(ax - hi, lo - ax)) <= 1e-7
+
+
 def test_lp_with_no_rows_goes_to_the_bounds():
     d = ktn.NLPDescription(3, [0], [], [], [], [], [], [], [], obj_linear=True, obj_col=[0, 1, 2],
                            obj_atom_kind=[0, 0, 0], obj_p0=[1.0, -2.0, 0.0], obj_p1=[0, 0, 0], obj_const=0.5)
