@@ -1352,7 +1352,9 @@ void Engine::rebuild_csc() {
     c_val.resize((size_t)NNZ + 1, stream);
     // (long columns: the merge orders a column's new entries by insertion -- fine for the 0.3 entries a column gains per sweep,
     //  quadratic for a column that gains one per cut; the radix sort does not care)
-    const bool few_per_col = col_gain_max <= (sharded_rows ? 8 : 64);      // (host-appended rows: other ranks' cuts come on top)
+    // (host-appended rows: the other ranks' cuts come on top -- as many ranks as the global NL-row count says, else 8)
+    const int64_t ranks = !sharded_rows ? 1 : (glists && m_nl > 0 ? (nl_total + m_nl - 1) / m_nl : 8);
+    const bool few_per_col = col_gain_max * ranks <= 128;
     if (!no_merge && n_longc == 0 && few_per_col && csc_epoch == lp_epoch && csc_M >= 0 && M >= csc_M && NNZ >= csc_NNZ && NNZ < ((int64_t)1 << 32)) {
         if (M > csc_M) csc_merge_appended();              // (M == csc_M: same structure, only the values are gathered again)
         stats["lp_csc_merges"] += 1.0;

@@ -123,7 +123,9 @@ def exchange_cuts_dev(dist, model, first_row, id_offset, scalars):
     if width == 0 or max_b >= 2.0:                            # nothing to move, or some rank's LP failed: the caller leaves the loop
         model.lp_truncate(first_row)
         return 0, max_a, max_b
-    send = torch.zeros(width, dtype=torch.float64, device="cuda")
+    # (torch.empty, not zeros: a fill kernel on torch's stream would race with the engine's pack kernel on ITS stream; the
+    #  padding behind a rank's 4 r + 2 z doubles is never read)
+    send = torch.empty(width, dtype=torch.float64, device="cuda")
     model.lp_pack_rows_dev(first_row, id_offset, send.data_ptr(), width)
     model.lp_truncate(first_row)
     recv = [torch.empty(width, dtype=torch.float64, device="cuda") for _ in range(world)]
