@@ -1036,7 +1036,9 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     // ---- upload the NLP
     d_rowptr.upload(h_rowptr, stream); d_col.upload(h_col, stream);
     max_row_len = 2;                                   // (the bound-box vertex row and other engine-made rows are short)
-    for (size_t i = 0; i + 1 < h_rowptr.size(); ++i) max_row_len = std::max(max_row_len, h_rowptr[i + 1] - h_rowptr[i]);
+    // (a LINEAR objective's row -- up to n entries -- is stored with the structure but never becomes an LP row: counting it made
+    //  every LP solve of cfg3 scan for long rows, a launch and a host round trip each)
+    for (int64_t i = 0; i < m0 + (obj_linear ? 0 : 1); ++i) max_row_len = std::max(max_row_len, h_rowptr[(size_t)i + 1] - h_rowptr[(size_t)i]);
     {
         // a cut has the sparsity of its NL row: the most entries ONE column can gain per sweep is the number of NL rows that
         // contain it (1-2 on the BASELINE shapes; m_nl for a variable every row shares -- min-max / epigraph-style models)
