@@ -306,6 +306,7 @@ struct Engine {
     int64_t n_longc = 0;
     int64_t col_gain_max = 0;                      // most NL rows sharing one column: what a column can gain per sweep
     int64_t col_len_max = -1, col_scan_rows = 0;   // longest column at the last scan, rows of the LP then (-1: never scanned)
+    int64_t col_removed_rows = 0;                  // rows purged / truncated since that scan (appended since = M - col_scan_rows + this)
     void find_long_cols();
     void spmv_cols(const SpMat& AT, const double* v, double* out, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
     static constexpr int kMaxChunk = 512;
@@ -1289,6 +1290,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     lp_c.upload(cvec, stream); lp_l.upload(lv, stream); lp_u.upload(uv, stream);
     lp_x.resize((size_t)n_lp, stream); lp_x.zero(stream);
     M_base = M; NNZ_base = NNZ; numcuts_base = numcuts; M_lin = n_lin;
+    n_longc = 0; col_len_max = -1; col_scan_rows = 0; col_removed_rows = 0;      // (a new problem: scan its columns at the first solve)
     {
         // room for three sweeps' worth of cuts (each sweep adds at most min(m_nl, cut cap) rows)
         int64_t per_sweep = m_nl;
@@ -1329,7 +1331,7 @@ void Engine::reset() {
     d_lastcut.upload(neg1, stream);
     d_age.resize((size_t)std::max<int64_t>(M, 1), stream);
     d_age.zero(stream);
-    lp_dirty = true; ++lp_version; ++lp_epoch; have_omega = false; have_precompute = false; sharded_rows = false; scal_rows = 0; smax_rows = 0; n_longc = 0; col_len_max = -1; col_scan_rows = 0;
+    lp_dirty = true; ++lp_version; ++lp_epoch; have_omega = false; have_precompute = false; sharded_rows = false; scal_rows = 0; smax_rows = 0; n_longc = 0; col_len_max = -1; col_scan_rows = 0; col_removed_rows = 0;
     blocks_built_rows = -1;
     if (d_blkomega.n) d_blkomega.zero(stream);
     if (ds_valid.n) ds_valid.zero(stream);
@@ -1397,8 +1399,9 @@ void Engine::rebuild_csc() {
 // Columns longer than kLongRow.  A column gains at most one entry per appended row, so between scans the longest possible
 // column is known on the host: no scan (and no round trip) while that bound stays below the threshold.
 void Engine::find_long_cols() {
-    if (col_len_max >= 0 && M >= col_scan_rows && n_longc == 0 && col_len_max + (M - col_scan_rows) <= kLongRow) return;
+    if (col_len_max >= 0 && n_longc == 0 && col_len_max + (M - col_scan_rows) + col_removed_rows <= kLongRow) return;
     n_longc = 0;
+    col_removed_rows = 0;
     if (M <= kLongRow || n_blocks > 0) { col_len_max = std::min<int64_t>(M, kLongRow); col_scan_rows = M; return; }
     d_longcols.resize((size_t)n_lp, stream);
     KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, 2 * sizeof(int32_t), stream));
@@ -1561,6 +1564,7 @@ void Engine::purge_cuts() {
     stats["purged_rows"] += (double)(m - m_new);
     purged_total += m - m_new;
     stats["purges"] += 1.0;
+    col_removed_rows += M - m_new;                     // (find_long_cols: a column may have gained as many entries as rows were appended)
     M = m_new; NNZ = nnz_new;
     lp_dirty = true; ++lp_version; ++lp_epoch;
 }
@@ -3239,6 +3243,7 @@ int ktn_lp_truncate(ktn_handle h, int64_t nrows) {
         KTN_HIP(hipMemcpyAsync(&base, e->lp_rowptr.p + nrows, 8, hipMemcpyDeviceToHost, e->stream));
         e->sync();
         e->numcuts -= (e->M - nrows);
+        e->col_removed_rows += e->M - nrows;
         e->M = nrows; e->NNZ = base;
         e->scal_rows = std::min(e->scal_rows, nrows);
         e->sharded_rows = true;
