@@ -1651,24 +1651,36 @@ bool Engine::build_tiled(TiledBuf& T, int64_t n_out, int64_t n_in, const int64_t
     T.nb_in = ceil_div(n_in, kTileIn);
     const size_t cells = (size_t)T.tiles * (size_t)T.nb_in;
     T.bptr.resize(cells * (kTileOut + 1), stream);
-    T.cur.resize(cells * (kTileOut + 1), stream);
-    T.bptr.zero(stream);
-    T.cur.zero(stream);
     T.segtot.resize(cells + 1, stream);
     T.segstart.resize(cells + 1, stream);
-    T.segtot.zero(stream);
-    KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
-    LAUNCH_1(k_tile_count, n_out, stream, n_out, ptr, idx, T.nb_in, skip_longer, T.bptr.p, d_anynf.p + 1);
-    hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)cells), dim3(kTileThreads), 0, stream, T.bptr.p, T.segtot.p, d_anynf.p + 1);
-    check_launch();
-    exclusive_scan(T.segtot.p, T.segstart.p, cells + 1);
     T.idx.resize((size_t)NNZ + 1, stream);
     T.val.resize((size_t)NNZ + 1, stream);
-    LAUNCH_1(k_tile_fill, n_out, stream, n_out, ptr, idx, val, T.nb_in, skip_longer, T.bptr.p, T.cur.p, T.segstart.p, T.idx.p, T.val.p);
-    check_launch();
     int32_t ovf = 0;
-    KTN_HIP(hipMemcpyAsync(&ovf, d_anynf.p + 1, 4, hipMemcpyDeviceToHost, stream));
-    sync();
+    const bool no_sorted = std::getenv("KTN_TILED_GENERAL_BUILD") != nullptr;             // (tests: the general kernels)
+    // first the run-based kernels (entries of an output in ascending input order: what the LP's rows and the mirror's columns
+    // are); an output that is not ascending makes them give up (bit 1) and the general kernels build the copy
+    for (int pass = no_sorted ? 1 : 0; pass < 2; ++pass) {
+        T.bptr.zero(stream);
+        T.segtot.zero(stream);
+        KTN_HIP(hipMemsetAsync(d_anynf.p + 1, 0, sizeof(int32_t), stream));
+        if (pass == 0) {
+            LAUNCH_1(k_tile_count_sorted, n_out, stream, n_out, ptr, idx, T.nb_in, skip_longer, T.bptr.p, d_anynf.p + 1);
+        } else {
+            T.cur.resize(cells * (kTileOut + 1), stream);
+            T.cur.zero(stream);
+            LAUNCH_1(k_tile_count, n_out, stream, n_out, ptr, idx, T.nb_in, skip_longer, T.bptr.p, d_anynf.p + 1);
+        }
+        hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)cells), dim3(kTileThreads), 0, stream, T.bptr.p, T.segtot.p, d_anynf.p + 1);
+        check_launch();
+        exclusive_scan(T.segtot.p, T.segstart.p, cells + 1);
+        if (pass == 0) LAUNCH_1(k_tile_fill_sorted, n_out, stream, n_out, ptr, idx, val, T.nb_in, skip_longer, T.bptr.p, T.segstart.p, d_anynf.p + 1, T.idx.p, T.val.p);
+        else LAUNCH_1(k_tile_fill, n_out, stream, n_out, ptr, idx, val, T.nb_in, skip_longer, T.bptr.p, T.cur.p, T.segstart.p, T.idx.p, T.val.p);
+        check_launch();
+        KTN_HIP(hipMemcpyAsync(&ovf, d_anynf.p + 1, 4, hipMemcpyDeviceToHost, stream));
+        sync();
+        if (pass == 0 && (ovf & 2)) { stats["lp_tiled_general_builds"] += 1.0; continue; }
+        break;
+    }
     // two 1024-thread workgroups per CU (80 KB of LDS each): a persistent grid over the (tile, block) units
     const int64_t U = T.tiles * T.nb_in;
     static const int wg_per_cu = std::getenv("KTN_TILED_WG") ? std::atoi(std::getenv("KTN_TILED_WG")) : 2;

@@ -1703,6 +1703,62 @@ __global__ __launch_bounds__(kBlock) void k_tile_fill(int64_t n_out, const int64
     }
 }
 
+// The same two passes for outputs whose entries come in ASCENDING input order (the rows of the LP -- linear rows and cuts are
+// stored by ascending column -- and the columns of the mirror, by ascending row): an output's entries of one input block are
+// then one RUN, so its count is a register (one store per run) and the fill needs no per-cell cursor -- the count pass had a
+// global read-modify-write per entry, the fill one plus two dependent loads (204 + 653 us per orientation on cfg4's LP).  An
+// output that is not ascending sets bit 1 of *overflow; the fill then does nothing and the host repeats the build with the
+// general kernels above.
+__global__ __launch_bounds__(kBlock) void k_tile_count_sorted(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                              int nb_in, int64_t skip_longer, uint16_t* __restrict__ cnt,
+                                                              int32_t* __restrict__ overflow) {
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (o >= n_out) return;
+    const int64_t beg = ptr[o], end = ptr[o + 1];
+    if (end - beg > skip_longer) return;
+    const int64_t tile = o / kTileOut;
+    const int t = (int)(o - tile * kTileOut);
+    int prev = -1;
+    uint32_t run = 0;
+    for (int64_t e = beg; e < end; ++e) {
+        const int b = idx[e] / kTileIn;
+        if (b != prev) {
+            if (b < prev) { atomicOr(overflow, 2); return; }
+            if (prev >= 0) cnt[(tile * nb_in + prev) * (kTileOut + 1) + t + 1] = (uint16_t)run;
+            prev = b;
+            run = 0;
+        }
+        if (++run > 0xFFFFu) { atomicOr(overflow, 1); return; }
+    }
+    if (prev >= 0) cnt[(tile * nb_in + prev) * (kTileOut + 1) + t + 1] = (uint16_t)run;
+}
+__global__ __launch_bounds__(kBlock) void k_tile_fill_sorted(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                             const double* __restrict__ val, int nb_in, int64_t skip_longer,
+                                                             const uint16_t* __restrict__ bptr, const int64_t* __restrict__ segstart,
+                                                             const int32_t* __restrict__ overflow, uint16_t* __restrict__ tidx,
+                                                             double* __restrict__ tval) {
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (o >= n_out || *overflow != 0) return;              // (counts of a non-ascending or overflowing build are not to be trusted)
+    const int64_t beg = ptr[o], end = ptr[o + 1];
+    if (end - beg > skip_longer) return;
+    const int64_t tile = o / kTileOut;
+    const int t = (int)(o - tile * kTileOut);
+    int prev = -1;
+    int64_t pos = 0;
+    for (int64_t e = beg; e < end; ++e) {
+        const int c = idx[e];
+        const int b = c / kTileIn;
+        if (b != prev) {
+            prev = b;
+            const int64_t tb = tile * nb_in + b;
+            pos = segstart[tb] + bptr[tb * (kTileOut + 1) + t];
+        }
+        tidx[pos] = (uint16_t)(c - b * kTileIn);
+        tval[pos] = val[e];
+        ++pos;
+    }
+}
+
 // ---------------------------------------------------------- diagonal scaling ------
 // Ruiz / Pock-Chambolle passes on the UNSCALED matrix with the current dr, dc:
 //   mode 0: out_i = dr_i * max_e |a_e| dc_col(e)     mode 1: out_i = dr_i * sum_e |a_e| dc_col(e)

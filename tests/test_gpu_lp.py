@@ -272,6 +272,45 @@ def test_tiled_spmv_steps_match_the_csr_steps():
     assert max_nl_violation(inst, m.getsolution()) <= 1e-6 * (1 + 1e-6)
 
 
+def test_run_based_tiled_build_equals_the_general_one_and_gives_way_to_it(monkeypatch):
+    """the tiled copies are built by run-based kernels (an output's entries of one input block are one run when they come in
+    ascending input order, as the LP's rows and the mirror's columns do): the same copy, bit for bit, as the general kernels
+    with their per-cell cursors; a row appended by the host with its columns in DESCENDING order makes the run-based build give
+    up and the general one take over -- same iterates as the CSR kernels either way"""
+    import numpy as np
+    from helpers import hip_load_instance
+    inst = ktn.instances.make_instance(n=20000, m_nl=60000, k=24, family="explog", seed=6)
+
+    def iterates(general, extra_row, tiled=1):
+        if general:
+            monkeypatch.setenv("KTN_TILED_GENERAL_BUILD", "1")
+        else:
+            monkeypatch.delenv("KTN_TILED_GENERAL_BUILD", raising=False)
+        m = hip_load_instance(ktn, inst, lp_tiled_nnz=tiled, cut_cap_factor=0.0, purge_age=0)
+        sep = ktn.KatanaHipSeparator(m); sep.initialize()
+        sep.precompute(np.clip(inst.xhat + 2.0, inst.l_var, inst.u_var))
+        sep.sweep(1e-6)
+        if extra_row:
+            cols = np.array([15000, 9000, 17, 3], dtype=np.int32)           # descending: crosses input blocks backwards
+            m.lp_append_rows(np.array([0, 4], dtype=np.int64), cols, np.array([1.0, -2.0, 0.5, 3.0]), np.array([-np.inf]), np.array([4.0]))
+        rng = np.random.default_rng(1)
+        x0, y0 = rng.uniform(-1, 1, m.num_var), np.abs(rng.standard_normal(m.lp_num_rows()))
+        _, _, _, lo, hi = m.lp_rows()
+        y0 = np.where(np.isfinite(lo), y0, -y0)
+        x, y = m.lp_pdhg_raw(x0, y0, 2e-3, 1.0, 25)
+        return x, y, m.stat("lp_tiled_builds"), m.stat("lp_tiled_general_builds")
+
+    xa, ya, ba, ga = iterates(False, False)
+    xb, yb, bb, gb = iterates(True, False)
+    assert ba == bb == 1 and ga == 0 and gb == 0
+    assert np.array_equal(xa, xb) and np.array_equal(ya, yb)
+    xc, yc, bc, gc = iterates(False, True)
+    xd, yd, *_ = iterates(False, True, tiled=0)                             # the CSR kernels on the same LP
+    assert bc == 1 and gc >= 1
+    assert np.max(np.abs(xc - xd)) <= 1e-11 * max(1.0, np.max(np.abs(xd)))
+    assert np.max(np.abs(yc - yd)) <= 1e-11 * max(1.0, np.max(np.abs(yd)))
+
+
 def test_append_only_mirror_update_gives_the_sorted_mirror_bit_for_bit(monkeypatch):
     """the column mirror of the growing LP: between purges it is extended by a merge of the appended rows (kernels.hpp
     "append-only update of the mirror") instead of a sort of all non-zeros.  Both give every column its entries in row order, so
