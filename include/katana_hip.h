@@ -103,7 +103,7 @@ typedef struct {
     /* GPU LP (restarted reflected Halpern PDHG) */
     int32_t lp_max_iter;    /* 10000000 PDHG iterations per LP solve                */
     int32_t lp_check_every; /* 64      iterations between KKT checks                */
-    int32_t lp_ruiz_iters;  /* 10                                                   */
+    int32_t lp_ruiz_iters;  /* 8   Ruiz (max-norm) passes before the Pock-Chambolle pass */
     double  lp_tol_scale;   /* 0.1     LP row tolerance = lp_tol_scale * max viol.  */
     double  lp_tol_floor;   /* 0.3     ... floored at lp_tol_floor * f_tol          */
     double  lp_tol_cap;     /* 10      ... capped                                   */

@@ -2958,7 +2958,7 @@ void ktn_default_params(ktn_params* p) {
     if (!p) return;
     p->f_tol = 1e-6; p->cut_coef_rng = 1e9; p->log_level = 10; p->iter_cap = 10000; p->obj_eps = -1.0;
     p->vis_data = 0; p->device = -1;
-    p->lp_max_iter = 10000000; p->lp_check_every = 64; p->lp_ruiz_iters = 10;
+    p->lp_max_iter = 10000000; p->lp_check_every = 64; p->lp_ruiz_iters = 8;
     p->lp_tol_scale = 0.1; p->lp_tol_floor = 0.3; p->lp_tol_cap = 10.0; p->lp_gap_floor = 1e-7; p->lp_gap_cap = 1e-2;
     p->lp_dual_inherit = 1; p->profile = 0;
     p->purge_age = 2; p->purge_margin = 1e-3; p->purge_min_frac = 0.05; p->purge_min_rows = 2000;
