@@ -71,6 +71,10 @@ int main(void) {
     EXPECT(ktn_dist_unique_id(NULL) == KTN_E_INVALID);
     memset(uid, 0, sizeof uid);
     EXPECT(ktn_dist_init_rccl(NULL, uid, 0, 1) == KTN_E_INVALID && ktn_dist_init_callback(NULL, 0, 1, cb, NULL) == KTN_E_INVALID);
+    EXPECT(ktn_dist_ipc_export(NULL, 0, 2, 64, uid) == KTN_E_INVALID && ktn_dist_init_ipc(NULL, 0, 2, uid) == KTN_E_INVALID);
+    EXPECT(ktn_dist_allreduce_probe(NULL, 8, 1, d8, d8) == KTN_E_INVALID);
+    EXPECT(ktn_objective_certificate(NULL, 0, d8) == KTN_E_INVALID);
+    EXPECT(ktn_lp_pack_rows_dev(NULL, 0, 0, d8, 8, i8, i8) == KTN_E_INVALID && ktn_lp_append_packed_dev(NULL, 0, 0, d8) == KTN_E_INVALID);
     printf("%s (%d failures)\n", fails ? "FAILED" : "ok", fails);
     return fails ? 1 : 0;
 }
