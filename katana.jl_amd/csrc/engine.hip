@@ -2242,7 +2242,6 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         // iterations; boosting eta by 5 % over the tight estimate stalls the method.  The slightly generous
         // cold estimate plus the back-off safeguard is the better operating point.)
         double* nrm = chkout.p + 2 * kChkQ + 1;
-        const bool warm = false;
         power_v.resize(n, stream);
         LAUNCH_1(k_hash_fill, n, stream, n, power_v.p);
         auto dot_dev = [&](const double* a, double* out) {
