@@ -62,7 +62,7 @@ def test_fast_path_equals_literal_path():
     assert abs(a.getobjval() - b.getobjval()) <= 1e-9 * max(1, abs(b.getobjval()))
 
 
-@pytest.mark.parametrize("family", ["explog", "quad"])
+@pytest.mark.parametrize("family", ["explog", "quad", "explog+t", "quad+t"])
 def test_oracle_finds_planted_optimum(family):
     inst = ktn.instances.make_instance(n=500, m_nl=50, k=16, family=family, seed=2)
     om = oracle_solve_instance(inst)
