@@ -1976,10 +1976,16 @@ void Engine::launch_x(const SpMat& AT, double tau, double w, double rho, bool up
         return;
     }
     if (n_longc > 0 && !(tiled_on && M > 0)) {
-        // long columns: A'y as a vector (lane groups + a workgroup per long column), then the element-wise primal step
-        spmv_cols(AT, yh.p, pv.p, e0, e1);
-        if (update) LAUNCH_1(k_x_prox<true>, n, stream, n, pv.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
-        else LAUNCH_1(k_x_prox<false>, n, stream, n, pv.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        // long columns: lane groups for the ordinary columns, a workgroup per long one -- the primal step fused into both
+        if (update) {
+            LAUNCH_GB(grp_cols, k_pdhg_x_skip, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho, kLongRow);
+            hipLaunchKernelGGL((k_pdhg_x_long<true>), dim3((unsigned)n_longc), dim3(1024), 0, stream, d_longcols.p, AT, yh.p, xh.p, x0h.p, xth.p,
+                               xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        } else {
+            LAUNCH_GB(grp_cols, k_pdhg_x_skip, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho, kLongRow);
+            hipLaunchKernelGGL((k_pdhg_x_long<false>), dim3((unsigned)n_longc), dim3(1024), 0, stream, d_longcols.p, AT, yh.p, xh.p, x0h.p, xth.p,
+                               xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        }
         return;
     }
     if (update) {

@@ -905,6 +905,52 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_x(int64_t n, SpMat AT, const do
     }
 }
 
+// The x-step of an LP with long columns (a variable every cut contains): lane groups for the ordinary columns, one
+// 1024-thread workgroup per long column (fixed-shape reduction: butterfly per wavefront, wavefronts in order).
+template <int G, bool UPDATE>
+__global__ __launch_bounds__(kBlock) void k_pdhg_x_skip(int64_t n, SpMat AT, const double* __restrict__ y,
+                                                        double* __restrict__ x, const double* __restrict__ x0,
+                                                        double* __restrict__ xt, double* __restrict__ xbar,
+                                                        const double* __restrict__ c, const double* __restrict__ l,
+                                                        const double* __restrict__ u, double tau, double w, double rho, int64_t skip_longer) {
+    const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+    const int lane = threadIdx.x & (G - 1);
+    if (j >= n) return;
+    const int64_t beg = AT.ptr[j], end = AT.ptr[j + 1];
+    if (end - beg > skip_longer) return;                  // k_pdhg_x_long
+    const double xv = x[j], cj = c[j], lj = l[j], uj = u[j], x0j = UPDATE ? x0[j] : 0.0;
+    double acc = 0.0;
+    for (int64_t e = beg + lane; e < end; e += G) acc += AT.val[e] * y[AT.idx[e]];
+    acc = group_sum<G>(acc);
+    if (lane == 0) {
+        const double xtv = clampd(xv - tau * (cj - acc), lj, uj);
+        if (UPDATE) { xbar[j] = 2.0 * xtv - xv; x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0j; }
+        else xt[j] = xtv;
+    }
+}
+template <bool UPDATE>
+__global__ __launch_bounds__(1024) void k_pdhg_x_long(const int32_t* __restrict__ cols, SpMat AT, const double* __restrict__ y,
+                                                      double* __restrict__ x, const double* __restrict__ x0,
+                                                      double* __restrict__ xt, double* __restrict__ xbar,
+                                                      const double* __restrict__ c, const double* __restrict__ l,
+                                                      const double* __restrict__ u, double tau, double w, double rho) {
+    __shared__ double sh[1024 / 64];
+    const int64_t j = cols[blockIdx.x];
+    double acc = 0.0;
+    for (int64_t e = AT.ptr[j] + threadIdx.x; e < AT.ptr[j + 1]; e += 1024) acc += AT.val[e] * y[AT.idx[e]];
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int k = 0; k < 1024 / 64; ++k) a += sh[k];
+        const double xv = x[j];
+        const double xtv = clampd(xv - tau * (c[j] - a), l[j], u[j]);
+        if (UPDATE) { xbar[j] = 2.0 * xtv - xv; x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0[j]; }
+        else xt[j] = xtv;
+    }
+}
+
 // ---- packed operands of the plain (update) steps ----------------------------------------------------------------
 // Per column the x-step reads (beg, len) as one 8-byte pair and (c, l, u, x0) as one 32-byte record instead of seven
 // separate arrays; per row the y-step reads (lo, hi, y0, beg | len) as one 32-byte record.  The records mirror ch / lh /
