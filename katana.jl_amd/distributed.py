@@ -65,8 +65,8 @@ def unpack_block(buf, nrows, nnz, with_ids=False):
 def exchange_cuts(dist, block, device="cpu", scalars=None):
     """All-gather one cut block per rank.  `block` = (rowptr, col, val, lo, hi[, ids]) of the local cuts.
     Returns the list of blocks in rank order.  With dist=None (single process) it is the identity.
-    `scalars` = (a, b): two floats that ride along with the size exchange; the call then returns
-    (blocks, max over ranks of a, max over ranks of b) -- the loop's status flags need no collective of their own."""
+    `scalars` = (a, b, ...): floats that ride along with the size exchange; the call then returns
+    (blocks, max over ranks of a, max over ranks of b, ...) -- the loop's status flags need no collective of their own."""
     import torch
     with_ids = len(block) == 6
     rowptr, col, val, lo, hi = block[:5]
@@ -74,17 +74,17 @@ def exchange_cuts(dist, block, device="cpu", scalars=None):
     nrows, nnz = len(lo), len(col)
     import os
     if dist is None or (dist.get_world_size() == 1 and not os.environ.get("KTN_FORCE_COLLECTIVE")):
-        return [block] if scalars is None else ([block], float(scalars[0]), float(scalars[1]))
+        return [block] if scalars is None else ([block],) + tuple(float(v) for v in scalars)
     world = dist.get_world_size()
-    sa, sb = (0.0, 0.0) if scalars is None else scalars
-    counts = torch.tensor([float(nrows), float(nnz), float(sa), float(sb)], dtype=torch.float64, device=device)
-    all_counts = [torch.zeros(4, dtype=torch.float64, device=device) for _ in range(world)]
-    dist.all_gather(all_counts, counts)                       # collective 1: sizes (+ the two scalars)
+    sc = () if scalars is None else tuple(float(v) for v in scalars)
+    counts = torch.tensor([float(nrows), float(nnz)] + list(sc), dtype=torch.float64, device=device)
+    all_counts = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts)                       # collective 1: sizes (+ the scalars)
     all_counts = [c.cpu() for c in all_counts]
-    max_a, max_b = max(float(c[2]) for c in all_counts), max(float(c[3]) for c in all_counts)
+    maxima = tuple(max(float(c[2 + k]) for c in all_counts) for k in range(len(sc)))
     all_counts = [(int(c[0]), int(c[1])) for c in all_counts]
     blocks = _gather_blocks(dist, device, world, all_counts, with_ids, rowptr, col, val, lo, hi, ids)
-    return blocks if scalars is None else (blocks, max_a, max_b)
+    return blocks if scalars is None else (blocks,) + maxima
 
 
 def _gather_blocks(dist, device, world, all_counts, with_ids, rowptr, col, val, lo, hi, ids):
@@ -107,22 +107,24 @@ def exchange_cuts_dev(dist, model, first_row, id_offset, scalars):
     into a torch CUDA tensor (ktn_lp_pack_rows_dev), `dist.all_gather` moves the padded blocks between the GPUs -- RCCL when
     the process group is "nccl"; a gloo group (tests: ranks sharing one GPU) cannot gather CUDA tensors and stages that one
     call through the host -- and every rank's block is appended from the receive buffer (ktn_lp_append_packed_dev).  Only
-    the four sizes / flags per rank cross to the host.  Returns (rows appended, max over ranks of scalars[0], of scalars[1]);
-    the model's own rows >= first_row are replaced by the gathered ones, in rank order."""
+    the sizes / flags per rank cross to the host.  Returns (rows appended, max over ranks of scalars[0], of scalars[1], ...);
+    the model's own rows >= first_row are replaced by the gathered ones, in rank order.  scalars[1] is the status flag: with
+    any rank at >= 2 nothing is moved."""
     import torch
     world = dist.get_world_size()
     nccl = dist.get_backend() == "nccl"
     nr, nz = model.lp_pack_rows_dev(first_row, id_offset)
-    counts = torch.tensor([float(nr), float(nz), float(scalars[0]), float(scalars[1])], dtype=torch.float64, device="cuda" if nccl else "cpu")
+    sc = [float(v) for v in scalars]
+    counts = torch.tensor([float(nr), float(nz)] + sc, dtype=torch.float64, device="cuda" if nccl else "cpu")
     all_counts = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(all_counts, counts)                       # collective 1: sizes (+ the two scalars)
+    dist.all_gather(all_counts, counts)                       # collective 1: sizes (+ the scalars)
     all_counts = [c.cpu() for c in all_counts]
-    max_a, max_b = max(float(c[2]) for c in all_counts), max(float(c[3]) for c in all_counts)
+    maxima = tuple(max(float(c[2 + k]) for c in all_counts) for k in range(len(sc)))
     sizes = [(int(c[0]), int(c[1])) for c in all_counts]
     width = max(4 * r + 2 * z for r, z in sizes)
-    if width == 0 or max_b >= 2.0:                            # nothing to move, or some rank's LP failed: the caller leaves the loop
+    if width == 0 or maxima[1] >= 2.0:                        # nothing to move, or some rank's LP failed: the caller leaves the loop
         model.lp_truncate(first_row)
-        return 0, max_a, max_b
+        return (0,) + maxima
     # (torch.empty, not zeros: a fill kernel on torch's stream would race with the engine's pack kernel on ITS stream; the
     #  padding behind a rank's 4 r + 2 z doubles is never read)
     send = torch.empty(width, dtype=torch.float64, device="cuda")
@@ -141,7 +143,7 @@ def exchange_cuts_dev(dist, model, first_row, id_offset, scalars):
     for r, (rows, nnz) in enumerate(sizes):                   # rank order => identical LP everywhere
         model.lp_append_packed_dev(rows, nnz, recv[r].data_ptr())
         total += rows
-    return total, max_a, max_b
+    return (total,) + maxima
 
 
 class ShardedKatanaModel:
@@ -195,10 +197,12 @@ class ShardedKatanaModel:
     def optimize_begin(self):
         self.m.optimize_begin()          # box-bounded shards: no presolve work, starts the solve timer
 
-    def _sweep_and_exchange(self, f_cut, lp_ok=True, lp_status="Optimal", purge=False):
+    def _sweep_and_exchange(self, f_cut, lp_ok=True, lp_status="Optimal", purge=False, extra=(0.0, 0.0)):
         """every rank sweeps its block of NL rows at the LP point (rows beyond f_cut get a cut), the cuts of all ranks are
-        appended in rank order.  Returns (cuts appended, largest violation, leave): `leave` = some rank's LP or sweep failed and
-        the status is set -- every rank sees the same flags and leaves in the same iteration."""
+        appended in rank order.  Returns (cuts appended, largest violation, leave, max over the ranks of each `extra`): `leave` =
+        some rank's LP or sweep failed and the status is set -- every rank sees the same flags and leaves in the same
+        iteration.  `extra`: two more floats whose maxima ride along (every decision of the loop is taken from quantities that
+        are the same on all ranks by construction, not merely by the determinism of identical LPs on identical GPUs)."""
         m0 = self.m.lp_num_rows()
         device_resident = self.exchange_device == "cuda" and self.dist is not None and self.world > 1
         block = None
@@ -218,16 +222,17 @@ class ShardedKatanaModel:
         # Two collectives per iteration.  The status flags ride with the size exchange: every rank must leave the loop in
         # the same iteration (one that returned early would leave the others waiting in the next collective).
         flag = (2.0 if not lp_ok else 0.0) + (1.0 if err_local else 0.0)
+        sc = (mv_local, flag) + tuple(extra)
         if device_resident:
-            nviol, maxviol, flags = exchange_cuts_dev(self.dist, self.m, m0, self.shard_lo, (mv_local, flag))
+            nviol, maxviol, flags, *ex = exchange_cuts_dev(self.dist, self.m, m0, self.shard_lo, sc)
             if flags >= 2.0:
                 self._status = lp_status if not lp_ok else "Error"
-                return 0, maxviol, True
+                return 0, maxviol, True, ex
         else:
-            blocks, maxviol, flags = exchange_cuts(self.dist, block, self.exchange_device, scalars=(mv_local, flag))
+            blocks, maxviol, flags, *ex = exchange_cuts(self.dist, block, self.exchange_device, scalars=sc)
             if flags >= 2.0:
                 self._status = lp_status if not lp_ok else "Error"
-                return 0, maxviol, True
+                return 0, maxviol, True, ex
             nviol = 0
             for rp, col, val, lo, hi, ids in blocks:             # rank order => identical LP everywhere
                 self.m.lp_append_rows(rp, col, val, lo, hi, ids)
@@ -235,8 +240,8 @@ class ShardedKatanaModel:
         self.exchanged_rows += nviol
         if flags >= 1.0:
             self._status = "Error"
-            return nviol, maxviol, True
-        return nviol, maxviol, False
+            return nviol, maxviol, True, ex
+        return nviol, maxviol, False, ex
 
     def _certificate(self):
         """sum over ALL NL rows of multiplier mass x signed residual (every rank adds its block; one tiny all-reduce), clamped"""
@@ -260,10 +265,6 @@ class ShardedKatanaModel:
         tol_p = min(max(self.tol["scale"] * self.last_maxviol, floor_p), self.tol["cap"])
         tol_g = min(max(tol_p, self.tol["gfloor"]), self.tol["gcap"])
         lp_status, _ = self.m.lp_solve(tol_p, tol_g)
-        nviol, maxviol, leave = self._sweep_and_exchange(f_tol, lp_status == "Optimal", lp_status, purge=True)
-        if leave:
-            return True
-        self.last_maxviol = maxviol
         # Engine::step's floor rule: satisfied at a loosely solved LP only counts when that solve already meets the floor
         # tolerances (or left through the stagnation exit with a gap the floor-tolerance solve would accept the same way)
         floor_g = min(max(floor_p, self.tol["gfloor"]), self.tol["gcap"])
@@ -271,6 +272,12 @@ class ShardedKatanaModel:
         gap = self.m.stat("lp_last_gap")
         at_floor = (self.m.stat("lp_last_row_viol") <= floor_p and self.m.stat("lp_last_dres_rel") <= floor_g and
                     (gap <= floor_g or (self.m.stat("lp_last_stag_exit") > 0 and stag > 0 and gap <= stag * floor_g)))
+        nviol, maxviol, leave, (not_floor, obj_all) = self._sweep_and_exchange(
+            f_tol, lp_status == "Optimal", lp_status, purge=True, extra=(0.0 if at_floor else 1.0, self.m.getobjval()))
+        if leave:
+            return True
+        at_floor = not_floor == 0.0                                # (the ranks' verdicts agree; taken from the exchange all the same)
+        self.last_maxviol = maxviol
         if nviol == 0 and tol_p > floor_p * (1 + 1e-12) and not at_floor:
             self.last_maxviol = 0.0                                # satisfied at a loosely solved LP: tighten first
         else:
@@ -283,7 +290,7 @@ class ShardedKatanaModel:
                 if 0.0 < prm.polish_factor < 1.0:
                     self._refining, self._phi, self._cert_target = True, prm.polish_factor, 0.0
             elif prm.obj_cert_tol > 0.0:
-                target = prm.obj_cert_tol * max(1.0, abs(self.m.getobjval()))
+                target = prm.obj_cert_tol * max(1.0, abs(obj_all))
                 d = self._certificate()
                 if d > 0.5 * target:
                     self._refining, self._cert_target = True, target
@@ -310,7 +317,7 @@ class ShardedKatanaModel:
         prm, f_tol = self.m.params, self.p["f_tol"]
         f_eff = self._phi * f_tol
         if self._pcount == 0:                    # first pass: measure (and cut at) the point that met the stop rule
-            nviol, mv, leave = self._sweep_and_exchange(f_eff)
+            nviol, mv, leave, _ = self._sweep_and_exchange(f_eff)
             if leave:
                 return True
             self._consider(mv)
@@ -331,7 +338,7 @@ class ShardedKatanaModel:
         lp_status, _ = self.m.lp_solve(tol_p, tol_g)
         if lp_status != "Optimal":               # (identical LPs: the same on every rank) keep the point that met the stop rule
             return self._finish_refinement()
-        nviol, mv, leave = self._sweep_and_exchange(f_eff)
+        nviol, mv, leave, _ = self._sweep_and_exchange(f_eff)
         if leave:
             return self._finish_refinement()
         self._consider(mv)
