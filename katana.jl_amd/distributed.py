@@ -204,7 +204,9 @@ class ShardedKatanaModel:
         iteration.  `extra`: two more floats whose maxima ride along (every decision of the loop is taken from quantities that
         are the same on all ranks by construction, not merely by the determinism of identical LPs on identical GPUs)."""
         m0 = self.m.lp_num_rows()
-        device_resident = self.exchange_device == "cuda" and self.dist is not None and self.world > 1
+        import os
+        device_resident = (self.exchange_device == "cuda" and self.dist is not None and
+                           (self.world > 1 or bool(os.environ.get("KTN_FORCE_COLLECTIVE"))))     # (forced: the one-rank RCCL test)
         block = None
         if lp_ok:
             if purge:
@@ -245,8 +247,9 @@ class ShardedKatanaModel:
 
     def _certificate(self):
         """sum over ALL NL rows of multiplier mass x signed residual (every rank adds its block; one tiny all-reduce), clamped"""
+        import os
         d = self.m.objective_certificate(self.shard_lo)
-        if self.dist is not None and self.world > 1:
+        if self.dist is not None and (self.world > 1 or os.environ.get("KTN_FORCE_COLLECTIVE")):
             import torch
             t = torch.tensor([d], dtype=torch.float64, device="cuda" if self.dist.get_backend() == "nccl" else "cpu")
             self.dist.all_reduce(t)

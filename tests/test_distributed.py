@@ -595,6 +595,41 @@ def test_rccl_transport_with_one_rank_gives_the_single_gpu_answer():
     assert np.max(np.abs(x - one.getsolution())) <= 1e-4
 
 
+def _worker_nccl_one_rank_replicated(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["KTN_FORCE_COLLECTIVE"] = "1"
+    import torch
+    import torch.distributed as dist
+    import katana_jl_amd as ktn
+    from katana_jl_amd.distributed import ShardedKatanaModel
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+                            device_id=torch.device("cuda", 0))
+    inst = ktn.instances.make_config("cfg3", seed=6)
+    m = ShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0), inst, rank, world, dist)
+    status = m.optimize()
+    out[rank] = (status, m.getobjval(), m.numiters(), m.exchange_device, m.exchanged_rows, m.stat("cert_refinements"), m.getsolution())
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_nccl_backend_with_one_rank_runs_the_device_resident_exchange():
+    """what `bench.py --gpus N` runs on cfg3, under the backend it runs it with: process group "nccl" (RCCL), cut blocks packed
+    into CUDA tensors, `dist.all_gather` of CUDA tensors, blocks appended from the receive buffers, the certificate's
+    all-reduce on a CUDA scalar -- with one rank (more need more GPUs than the box has) every gather returns the rank's own
+    block, so the solve must be the single-GPU one bit for bit, refinement included (cfg3 seed 6)"""
+    import katana_jl_amd as ktn
+    from helpers import assert_planted_objective, hip_load_instance
+    out = mp.Manager().dict()
+    mp.spawn(_worker_nccl_one_rank_replicated, args=(1, _free_port(), out), nprocs=1, join=True)
+    status, obj, iters, exch, rows, refinements, x = out[0]
+    inst = ktn.instances.make_config("cfg3", seed=6)
+    one = hip_load_instance(ktn, inst)
+    assert one.optimize() == status == "Optimal" and exch == "cuda" and rows > 0 and refinements == 1
+    assert obj == one.getobjval() and iters == one.numiters() and np.array_equal(x, one.getsolution())
+    assert_planted_objective(obj, inst)
+
+
 def test_both_sharded_models_offer_what_bench_reads():
     """bench.py's multi_gpu block reads these from whichever model `--replicated-lp` selects"""
     from katana_jl_amd.distributed import RowShardedKatanaModel, ShardedKatanaModel
