@@ -262,7 +262,10 @@ def main():
     torch.cuda.set_device(local_rank)
     import katana_jl_amd as ktn
     dist = None
-    if world > 1:
+    # KTN_FORCE_COLLECTIVE=1 with one rank: the N > 1 code path (process group, sharded model, collectives, multi_gpu block) on
+    # a one-GPU box -- every gather returns the rank's own block; a rehearsal of the nccl branch, not a measurement
+    multi_path = world > 1 or bool(os.environ.get("KTN_FORCE_COLLECTIVE"))
+    if multi_path:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -272,10 +275,10 @@ def main():
     if args.workload == "cfg5":
         return main_batch(args, ktn, torch, dist, rank, world, local_rank, backend)
     inst = ktn.instances.make_config(args.workload, seed=args.seed)
-    if world > 1 and args.replicated_lp:
+    if multi_path and args.replicated_lp:
         from katana_jl_amd.distributed import ShardedKatanaModel
         model = ShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=local_rank), inst, rank, world, dist)
-    elif world > 1:
+    elif multi_path:
         from katana_jl_amd.distributed import RowShardedKatanaModel
         model = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=local_rank), inst, rank, world, dist, transport=args.transport)
     else:
@@ -316,7 +319,7 @@ def main():
     iters_to_ftol = model.numiters()
 
     roofline = None
-    if world == 1 and not args.no_roofline:
+    if not multi_path and not args.no_roofline:
         # identical second pass with per-launch hipEvent timing on the engine's stream
         prof = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, device=local_rank, profile=1))
         prof.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense,
@@ -362,7 +365,7 @@ def main():
     # the separator sweep on the HBM-resident variant of the same workload (k = 2048 entries per
     # NL row, 411 MB per pass); at cfg3's own k = 32 the sweep is a 10 us launch-latency-bound kernel.
     sweep_roofline = None
-    if world == 1 and not args.no_roofline and not args.no_sweep_roofline and args.workload == "cfg3":
+    if not multi_path and not args.no_roofline and not args.no_sweep_roofline and args.workload == "cfg3":
         hb = ktn.instances.make_config("cfg3_hbm", seed=args.seed, vertex=False)
         sm = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, device=local_rank, profile=1))
         sm.loadproblem(hb.n, hb.num_constr, hb.l_var, hb.u_var, hb.l_constr, hb.u_constr, hb.sense, ktn.SeparableNLP(hb))
@@ -399,7 +402,7 @@ def main():
     # The box's practical streaming ceilings next to the 8 TB/s spec figure `peak` ("quote the copy-kernel
     # ceiling measured in the same run"): a read-only reduction and a copy over 1 GiB, plain torch kernels
     stream_ceiling = None
-    if world == 1 and not args.no_roofline and rank == 0:
+    if not multi_path and not args.no_roofline and rank == 0:
         nel = (1 << 30) // 8
         xs_ = torch.ones(nel, dtype=torch.float64, device="cuda")
         ys_ = torch.empty_like(xs_)
@@ -420,7 +423,7 @@ def main():
     # The LP SpMV steps in the HBM regime (tools/spmv_bench.py): cfg4's LP after one un-capped sweep
     spmv_roofline = None
     sweep_short = None
-    if world == 1 and not args.no_roofline and not args.no_spmv_roofline and args.workload == "cfg3":
+    if not multi_path and not args.no_roofline and not args.no_spmv_roofline and args.workload == "cfg3":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import spmv_bench
         sinst, sm, nviol = spmv_bench.build(1_000_000, device=local_rank)
@@ -483,13 +486,13 @@ def main():
         del sm, sinst
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi_path and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
     # N > 1: the per-phase split of the timed region, the latency of one all-reduce of an n-vector on this fabric, and the
     # SAME workload on rank 0's GPU alone (what a strong-scaling ratio has to be taken against)
     multi = None
-    if world > 1:
+    if multi_path:
         t = torch.zeros(inst.n + 1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         for _ in range(5):
             dist.all_reduce(t)
@@ -532,7 +535,7 @@ def main():
                                    "planted non-degenerate vertex optimum, f_tol=1e-6" % (
                                        args.workload, inst.n, inst.m_lin, inst.m_nl, inst.meta["family"], inst.meta["k"],
                                        args.seed),
-                       "parallelism": "1 GPU" if world == 1 else (
+                       "parallelism": "1 GPU" if not multi_path else (
                            "nl-rows sharded x%d, replicated LP, all-gather of cuts" % world if args.replicated_lp else
                            "rows sharded x%d (linear rows and NL rows by blocks, cuts stay on their rank), x replicated, "
                            "one all-reduce of an n-vector per PDHG iteration (transport: %s)" % (world, model.transport))},
