@@ -2563,7 +2563,12 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             const double dx = std::sqrt(dx0sq), dy = std::sqrt(dy0sq);
             // guarded primal-weight update (oracle/pdlp_mirror.py solve_lp_halpern)
             if (dx > 1e-8 * (1.0 + std::sqrt(xt2)) && dy > 1e-8 * (1.0 + std::sqrt(yt2))) {
+                static const double om_clamp = std::getenv("KTN_OMEGA_CLAMP") ? std::atof(std::getenv("KTN_OMEGA_CLAMP")) : 0.0;
+                const double om_old = om;
                 om = std::exp(0.5 * std::log(dy / dx) + 0.5 * std::log(om));
+                static const double om_clamp_dn = std::getenv("KTN_OMEGA_CLAMP_DOWN") ? std::atof(std::getenv("KTN_OMEGA_CLAMP_DOWN")) : 0.0;
+                if (om_clamp > 1.0) om = std::min(std::max(om, om_old / om_clamp), om_old * om_clamp);
+                if (om_clamp_dn > 1.0) om = std::max(om, om_old / om_clamp_dn);
                 om = std::min(std::max(om, omega_ref * 1e-3), omega_ref * 1e3);
             }
             LAUNCH_1(k_restart_set, std::max(n, m), stream, n, m, xth.p, xh.p, x0h.p, yth.p, yh.p, y0h.p, packed_on ? d_crec.p : (ColRec*)nullptr,
