@@ -2511,6 +2511,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             }
         }
         bool restart = k > 0 && (r <= 0.2 * r0 || (r <= 0.8 * r0 && r > r_prev) || (double)k >= 0.36 * (double)(it + 1));
+        const bool decayed = r <= 0.8 * r0;             // (a restart that the residual earned; the artificial one below is by the clock)
         // step-size safeguard: a fixed-point residual that no longer moves (or a negative M-norm) while
         // the LP is not solved means eta * sigma_max > 1 -> shrink eta and restart from the current point
         if (k > 0 && eta > eta_safe * (1.0 + 1e-12)) {
@@ -2562,7 +2563,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         if (restart) {
             const double dx = std::sqrt(dx0sq), dy = std::sqrt(dy0sq);
             // guarded primal-weight update (oracle/pdlp_mirror.py solve_lp_halpern)
-            if (dx > 1e-8 * (1.0 + std::sqrt(xt2)) && dy > 1e-8 * (1.0 + std::sqrt(yt2))) {
+            static const int om_art = std::getenv("KTN_OMEGA_ART") ? std::atoi(std::getenv("KTN_OMEGA_ART")) : 1;
+            if ((om_art || decayed) && dx > 1e-8 * (1.0 + std::sqrt(xt2)) && dy > 1e-8 * (1.0 + std::sqrt(yt2))) {
                 static const double om_clamp = std::getenv("KTN_OMEGA_CLAMP") ? std::atof(std::getenv("KTN_OMEGA_CLAMP")) : 0.0;
                 const double om_old = om;
                 om = std::exp(0.5 * std::log(dy / dx) + 0.5 * std::log(om));
