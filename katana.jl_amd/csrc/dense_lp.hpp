@@ -268,7 +268,35 @@ __global__ __launch_bounds__(256) void k_dense_lp(DenseLpIO P) {
             s_p = p;
         }
         __syncthreads();
-        if (s_p < 0) { status = 1; break; }            // no side can leave: the LP is infeasible
+        if (s_p < 0) {
+            // No side can leave: the dual ray -u proves infeasibility -- of the LP INSIDE its artificial sides.  The stand-in bound
+            // of a free variable starts at 0 and is no constraint of the LP, so a ray that puts weight on one (u_r < 0) proves
+            // nothing yet (fuzz models 55/106, 144/51: feasible LPs with free variables reported infeasible).  Those sides are
+            // pushed outwards -- far enough to satisfy the entering side, at least tenfold, at most to kDenseBig -- and the
+            // iteration goes on with the same working set and multipliers.  A ray that survives bounds of 1e7 is taken as the
+            // certificate (fuzz models 2/62, 2/138: infeasible, and said so by the oracle's simplex).
+            if (t == 0) {
+                double nrm;
+                const double excess = fmax(dense_side_dot(P, q_in, xs, &nrm) - dense_side_rhs(P, q_in), 0.0);
+                int grown = 0;
+                for (int r = 0; r < n; ++r) {
+                    const int k = Ws[r];
+                    if (k >= 0 || !(uvec[r] < -1e-11)) continue;
+                    const int j = (-1 - k) >> 1;
+                    const double b = ((-1 - k) & 1) ? -P.l[j] : P.u[j];
+                    if (b < kDenseBig) continue;               // a real bound
+                    double& a = art[-1 - k];
+                    if (a >= kDenseBig) continue;
+                    a = fmin(fmax(fmax(10.0 * a, 1.0), a + 2.0 * excess / (-uvec[r]) + 1.0), kDenseBig);
+                    grown = 1;
+                }
+                s_flag = grown;
+            }
+            __syncthreads();
+            if (!s_flag) { status = 1; break; }        // a certificate on real sides (or on artificial ones at 1e7): infeasible
+            __syncthreads();
+            continue;
+        }
         if (t == 0) Ws[s_p] = (int)q_in;
         __syncthreads();
     }

@@ -2086,18 +2086,10 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
     const bool dense_ok = mode == 0 && !identity_scaling && !row_sharded() && prm.lp_dense_after != 0 && n_lp >= 1 && n_lp <= kDenseMaxN &&
                           M * n_lp <= 8000000;
     if (!dense_ok) return lp_solve_core(tol_p, tol_g, mode, identity_scaling);
-    // The exact kernel's ":Infeasible" is a verdict of its pivoting tolerances on what can be a nearly degenerate LP (fuzz model
-    // 55/106: several nearly parallel cuts at a curved optimum, reported infeasible at ECP iteration 28 where the oracle goes on to
-    // :Optimal): it is only passed on when the first-order method's Farkas test (two consecutive checks, section 5) agrees.
-    auto confirmed = [&](const LpResult& D) {
-        if (D.status != KTN_STATUS_INFEASIBLE) return D;
-        stats["dense_lp_infeasible_checks"] += 1.0;
-        return lp_solve_core(tol_p, tol_g, mode, identity_scaling);
-    };
     if (prm.lp_dense_after < 0 || dense_credit > 0) {
         if (dense_credit > 0) --dense_credit;
         LpResult R;
-        if (lp_solve_dense(&R)) return confirmed(R);
+        if (lp_solve_dense(&R)) return R;
         stats["dense_lp_fallbacks"] += 1.0;
         return lp_solve_core(tol_p, tol_g, mode, identity_scaling);
     }
@@ -2110,7 +2102,7 @@ LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_sc
     if (lp_solve_dense(&D)) {
         dense_run = std::min<int64_t>(2 * std::max<int64_t>(dense_run, 1), 1 << 20);
         dense_credit = dense_run;
-        return confirmed(D);
+        return D;
     }
     stats["dense_lp_fallbacks"] += 1.0;
     return lp_solve_core(tol_p, tol_g, mode, identity_scaling);

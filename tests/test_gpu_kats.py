@@ -159,7 +159,18 @@ def test_failing_evaluator_callback_surfaces_as_an_error_code():
     assert "eval_rows callback failed" in str(ei.value)
 
 
-@pytest.mark.parametrize("seed,index", [(2, 109), (13, 142)])
+@pytest.mark.parametrize("seed,index", [(2, 62), (2, 138)])
+def test_infeasible_fuzz_models_stay_infeasible(seed, index):
+    """two members of the stream that ARE infeasible (the oracle's simplex says so): the exact kernel pushes the artificial sides of
+    their free variables out to 1e7 before it takes its dual ray for a certificate, and still reports them infeasible"""
+    from fuzz_models import model_at
+    from helpers import oracle_solve_kat
+    m = model_at(seed, index)
+    M = hip_model_from_kat(ktn, m, lp_max_iter=400000)
+    assert M.solve() == oracle_solve_kat(m).getstatus() == "Infeasible"
+
+
+@pytest.mark.parametrize("seed,index", [(2, 109), (13, 142), (55, 106), (144, 51)])
 def test_fuzz_models_that_once_failed(seed, index):
     """Two members of the random small-model stream (tests/fuzz_models.py; 1 500 models against the oracle at the end of round 3)
     that the engine got wrong -- both with free variables and a quadratic objective, i.e. inside the presolve's territory
@@ -167,7 +178,9 @@ def test_fuzz_models_that_once_failed(seed, index):
     1e13 away, whose cuts (constants of 1e31) no first-order LP survives: :Error -- models with free variables keep the
     conservative exit now.  13/142: the recession LP (6 rows, 5 columns, tolerance 1e-9) exhausted the first-order iteration
     limit, "no ray" was concluded and the main LP ran along the missed ray to ITS limit: :UserLimit -- the recession LP of a
-    small model is solved by the exact kernel now.  The oracle (serial restatement + simplex) ends :Optimal on both."""
+    small model is solved by the exact kernel now.  55/106 (:Infeasible) and 144/51 (21 s): the exact kernel took a dual ray that
+    put weight on the ARTIFICIAL side of a free variable for an infeasibility certificate -- such sides are pushed outwards (up
+    to 1e7) and the pivoting continues.  The oracle (serial restatement + simplex) ends :Optimal on all four."""
     from fuzz_models import model_at
     from helpers import oracle_solve_kat
     m = model_at(seed, index)
