@@ -70,6 +70,23 @@ def test_oracle_finds_planted_optimum(family):
     assert abs(om.getobjval() - inst.opt_obj) <= 1e-5 * max(1.0, abs(inst.opt_obj))
 
 
+@pytest.mark.parametrize("seed,index,nv,ncons,status,obj,iters", [
+    (2, 109, 4, 3, "Optimal", -5.129864387562447e-07, 75), (13, 142, 4, 2, "Optimal", 0.010341655863652294, 56),
+    (55, 106, 3, 1, "Optimal", 1.4213188826617347, 33), (144, 51, 4, 4, "Optimal", 0.9446566311142093, 30),
+    (2, 62, 5, 4, "Infeasible", None, 9), (2, 138, 6, 4, "Infeasible", None, 17)])
+def test_fuzz_regression_models_are_pinned(seed, index, nv, ncons, status, obj, iters):
+    """the six members of the random small-model stream (tests/fuzz_models.py) that the GPU suite replays: the generator gives the
+    same models as when they were found, and the oracle the same status / objective / iteration count"""
+    from fuzz_models import model_at
+    from helpers import oracle_solve_kat
+    m = model_at(seed, index)
+    assert len(m["vars"]) == nv and len(m["constraints"]) == ncons and all(v["ub"] == float("inf") for v in m["vars"])
+    om = oracle_solve_kat(m)
+    assert om.getstatus() == status and om.numiters() == iters
+    if obj is not None:
+        assert abs(om.getobjval() - obj) <= 1e-9 * max(1.0, abs(obj))
+
+
 def test_round_coefs_signed_max_and_constant_untouched():
     from oracle.katana import AffExpr, round_coefs
     cut = AffExpr([0, 1, 2], [-2e9, 1.0, -5.0], 7.0)
