@@ -13,8 +13,9 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
 ONLY = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 MAXIT = int(sys.argv[4]) if len(sys.argv) > 4 else 2000000
+NV_LO, NV_HI = (int(v) for v in os.environ.get("FUZZ_NV", "2,7").split(","))     # (the replayed regressions use the default range)
 for t in range(N):
-    m = rand_model(rng, int(rng.integers(2, 7)), boxed=rng.random() < 0.5)
+    m = rand_model(rng, int(rng.integers(NV_LO, NV_HI)), boxed=rng.random() < 0.5)
     if ONLY >= 0 and t != ONLY:
         continue
     if m["sense"] == "Max":
