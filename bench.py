@@ -51,7 +51,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r03"      # profiles/<round>_kernel_stats.csv, <round>_traffic.json: the rocprofv3 summaries of THIS command
+PROFILE_ROUND = "r04"      # profiles/<round>_kernel_stats.csv, <round>_traffic.json: the rocprofv3 summaries of THIS command
+
+
+def csrc_sha16():
+    """Content hash of the kernel sources (katana.jl_amd/csrc/*.hip, *.hpp): profiles/<round>_source.json records the hash (and
+    the git commit) the committed rocprofv3 summaries were made from -- tools/stamp_profiles.py -- and a summary whose hash is
+    not the hash of the sources this run was built from is STALE and is not quoted."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "katana.jl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "katana.jl_amd", "csrc", "*.hpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_stamp():
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_source.json")
+    if not os.path.exists(path):
+        return None
+    st = json.load(open(path))
+    st["fresh"] = st.get("csrc_sha16") == csrc_sha16()
+    return st
 
 
 def rocprof_avg_ns(csv_name, kernel_prefix):
@@ -72,17 +94,24 @@ def rocprof_avg_ns(csv_name, kernel_prefix):
 
 
 def with_rocprof(r, csv_name, kernel_prefix):
-    """`frac` / `achieved` of a roofline record from the rocprofv3 duration of the same kernel in profiles/ (profiled passes run
-    a little slower than the in-process hipEvents: the conservative figure is the headline, the live one stays beside it)."""
-    r["achieved_inprocess"], r["frac_inprocess"] = r["achieved"], r["frac"]
+    """`achieved` / `frac` of a roofline record stay what THIS run measured (per-launch hipEvents on the engine's stream).  Beside
+    them, as `frac_rocprof_committed`, the same algorithmic bytes over the mean duration of the kernel in the committed
+    rocprofv3 summary -- only when profiles/<round>_source.json says the summary was made from the very sources this run was
+    built from (csrc_sha16); a stale summary is named as such and not quoted."""
+    r["achieved_inprocess"], r["frac_inprocess"] = r["achieved"], r["frac"]      # (the names of rounds 2-3, kept for the record)
+    r["frac_source"] = "this run: algorithmic bytes per launch / mean launch duration, hipExtLaunchKernelGGL start/stop events on the engine's stream"
+    st = profile_stamp()
     ns = rocprof_avg_ns(csv_name, kernel_prefix)
-    if ns:
+    r["frac_rocprof_committed"] = None
+    if ns and st and st["fresh"]:
         r["avg_launch_us_rocprof"] = ns / 1e3
-        r["achieved"] = r["algorithmic_bytes_per_launch"] / (ns * 1e-9) / 1e9
-        r["frac"] = r["achieved"] / HBM_PEAK_GBS
-        r["frac_source"] = "algorithmic bytes of this run / mean duration of %s in profiles/%s (rocprofv3 --kernel-trace --stats of this command)" % (kernel_prefix, csv_name)
+        r["frac_rocprof_committed"] = r["algorithmic_bytes_per_launch"] / (ns * 1e-9) / 1e9 / HBM_PEAK_GBS
+        r["rocprof_source"] = "profiles/%s, made at commit %s from sources %s (= this build)" % (csv_name, st.get("git_head"), st.get("csrc_sha16"))
+    elif ns and st:
+        r["rocprof_source"] = "profiles/%s is STALE: made from sources %s (commit %s), this build is %s -- not quoted" % (
+            csv_name, st.get("csrc_sha16"), st.get("git_head"), csrc_sha16())
     else:
-        r["frac_source"] = "in-process hipEvents (no profiles/%s)" % csv_name
+        r["rocprof_source"] = "no profiles/%s (or no %s_source.json stamp)" % (csv_name, PROFILE_ROUND)
     return r
 
 
@@ -282,15 +311,40 @@ def main():
         from katana_jl_amd.distributed import RowShardedKatanaModel
         model = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=local_rank), inst, rank, world, dist, transport=args.transport)
     else:
+        # What a user of the reference pays (soltime spans all of optimize!, src/model.jl:227,311, and a JuMP `solve` pays
+        # loadproblem! every time, src/model.jl:81-173): a fresh handle, the load and the first solve, COLD -- before any warm-up,
+        # first touch of the device allocator included.  The timed steps below then run from this handle's loaded state.
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        nlp = ktn.SeparableNLP(inst)
+        tc1 = time.perf_counter()
         model = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, device=local_rank))
-        model.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense,
-                          ktn.SeparableNLP(inst))
+        model.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense, nlp)
+        tc2 = time.perf_counter()
+        st_first = model.optimize()
+        tc3 = time.perf_counter()
+        cold = {"first_solve_s": tc3 - tc1, "first_load_s": tc2 - tc1, "first_optimize_s": tc3 - tc2, "describe_s": tc1 - tc0,
+                "status": st_first, "ecp_iters": model.numiters(),
+                "what": "fresh ktn_create + ktn_loadproblem + ktn_optimize on a cold process, host buffers in, before any warm-up"}
+        # ... and the same load with the allocator warm (a second problem on a live process): median of 3 on a second handle
+        m2 = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, device=local_rank))
+        loads = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            m2.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense, nlp)
+            loads.append(time.perf_counter() - tl)
+        cold["load_s"] = sorted(loads)[1]
+        del m2
+        model.reset()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if multi_path:
+        cold = None
     run_steps(model, args.warmup)
     barrier()
     solves = []
@@ -351,7 +405,7 @@ def main():
         # HBM traffic from the PMC counters cannot be collected in-process; the per-launch figure of the committed
         # rocprofv3 --pmc passes over this same command is reported (profiles/r02_traffic.json, regenerated every round)
         tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_traffic.json")
-        if os.path.exists(tpath) and args.workload == "cfg3":
+        if os.path.exists(tpath) and args.workload == "cfg3" and (profile_stamp() or {}).get("fresh"):
             t = json.load(open(tpath))
             key = "k_pdhg_x" if dom == "kx" else "k_pdhg_y"
             if key in t:
@@ -392,11 +446,13 @@ def main():
         # the sweep is two kernels per pass (blocked evaluation + combination): the rocprofv3 figure is the sum of their means
         ns_blk, ns_cmb = rocprof_avg_ns(PROFILE_ROUND + "_sweep_hbm_kernel_stats.csv", "k_sep_eval_blk"), rocprof_avg_ns(PROFILE_ROUND + "_sweep_hbm_kernel_stats.csv", "k_sep_combine")
         sweep_roofline["achieved_inprocess"], sweep_roofline["frac_inprocess"] = sweep_roofline["achieved"], sweep_roofline["frac"]
-        if ns_blk and ns_cmb:
+        sweep_roofline["frac_source"] = "this run (per-launch hipEvents)"
+        st = profile_stamp()
+        sweep_roofline["frac_rocprof_committed"] = None
+        if ns_blk and ns_cmb and st and st["fresh"]:
             sweep_roofline["avg_launch_us_rocprof"] = (ns_blk + ns_cmb) / 1e3
-            sweep_roofline["achieved"] = sweep_roofline["algorithmic_bytes_per_launch"] / ((ns_blk + ns_cmb) * 1e-9) / 1e9
-            sweep_roofline["frac"] = sweep_roofline["achieved"] / HBM_PEAK_GBS
-            sweep_roofline["frac_source"] = "profiles/%s_sweep_hbm_kernel_stats.csv (k_sep_eval_blk + k_sep_combine)" % PROFILE_ROUND
+            sweep_roofline["frac_rocprof_committed"] = sweep_roofline["algorithmic_bytes_per_launch"] / ((ns_blk + ns_cmb) * 1e-9) / 1e9 / HBM_PEAK_GBS
+            sweep_roofline["rocprof_source"] = "profiles/%s_sweep_hbm_kernel_stats.csv (k_sep_eval_blk + k_sep_combine), commit %s" % (PROFILE_ROUND, st.get("git_head"))
         del sm, sep, hb
 
     # The box's practical streaming ceilings next to the 8 TB/s spec figure `peak` ("quote the copy-kernel
@@ -448,14 +504,15 @@ def main():
             rec = spmv_roofline["kernels"][name]
             rec["achieved_inprocess"], rec["frac_inprocess"] = rec["achieved"], rec["frac"]
             ns_e = rocprof_avg_ns(PROFILE_ROUND + "_spmv_hbm_kernel_stats.csv", epi)
-            if ns_t and ns_e and spmv_roofline["tiled"]:
+            st = profile_stamp()
+            rec["frac_rocprof_committed"] = None
+            if ns_t and ns_e and spmv_roofline["tiled"] and st and st["fresh"]:
                 rec["avg_step_us_rocprof"] = (ns_t + ns_e) / 1e3
-                rec["achieved"] = rec["algorithmic_bytes_per_step"] / ((ns_t + ns_e) * 1e-9) / 1e9
-                rec["frac"] = rec["achieved"] / HBM_PEAK_GBS
+                rec["frac_rocprof_committed"] = rec["algorithmic_bytes_per_step"] / ((ns_t + ns_e) * 1e-9) / 1e9 / HBM_PEAK_GBS
         worst = min(spmv_roofline["kernels"].values(), key=lambda r: r["frac"])
         spmv_roofline["achieved"], spmv_roofline["frac"] = worst["achieved"], worst["frac"]
         spmv_roofline["frac_inprocess"] = min(r["frac_inprocess"] for r in spmv_roofline["kernels"].values())
-        spmv_roofline["frac_source"] = "profiles/%s_spmv_hbm_kernel_stats.csv where present (k_spmv_tiled + epilogue), else in-process hipEvents" % PROFILE_ROUND
+        spmv_roofline["frac_source"] = "this run (per-launch hipEvents, the worse of the two steps); frac_rocprof_committed per step from profiles/%s_spmv_hbm_kernel_stats.csv when its stamp matches this build" % PROFILE_ROUND
         tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_traffic.json")
         if os.path.exists(tpath):
             t = json.load(open(tpath)).get("k_spmv_tiled")
@@ -542,6 +599,8 @@ def main():
             "wall_to_ftol_s": wall_to_ftol, "ecp_iters_to_ftol": iters_to_ftol, "status": status, "objective": obj,
             "planted_objective": inst.opt_obj, "objective_relerr": abs(obj - inst.opt_obj) / max(1.0, abs(inst.opt_obj)),
             "pdhg_iters_per_step": pdhg_timed / args.steps, "solves_in_timed_region": len(solves),
+            "first_solve_s": cold["first_solve_s"] if cold else None, "load_s": cold["load_s"] if cold else None, "cold": cold,
+            "job_rate_incl_load": (iters_to_ftol / (cold["load_s"] + wall_to_ftol)) if cold else None,
             "roofline": roofline, "sweep_roofline": sweep_roofline, "sweep_roofline_short_rows": sweep_short,
             "spmv_roofline": spmv_roofline, "stream_ceiling": stream_ceiling,
             "cpu_baseline": cpu,

@@ -163,6 +163,14 @@ typedef struct {
        obj_cert_tol * max(1, |objective|).  The reference's tests accept an objective within 1e-6 (test/runtests.jl:16-17); its exact
        simplex vertices end Kelley's method far below f_tol, a first-order LP ends AT f_tol times the multipliers.              */
     double  obj_cert_tol;   /* 1e-6    (refines while the sum exceeds half of it)  0 = stop at the reference's rule alone          */
+    /* exact mid-size LP solver (csrc/mid_lp.hpp): LPs of 33 .. lp_mid_max_var columns are handed to a dual active-set method with
+       the basis inverse in device memory when the first-order method stalls (same hand-over rule as lp_dense_after: the LPs of
+       a cutting-plane run on a smooth-face optimum -- the reference's own regime, README.md:5 -- have many nearly parallel cuts
+       active at once, which the reference's warm-started simplex re-solves in a handful of pivots, src/model.jl:259)            */
+    int32_t lp_mid_max_var; /* 512     largest LP (columns) handed over; at most 4096 (n x n doubles of basis inverse); 0 = never.
+                                       A pivot costs O(n^2) and a Kelley re-solve hundreds of pivots (the LP vertex jumps), so
+                                       beyond a few hundred columns the hand-over stops paying (DESIGN.md section 5
+                                       "Smooth-face optima")                                                                    */
 } ktn_params;
 
 /* The device-evaluable statement of the NLP: replaces the

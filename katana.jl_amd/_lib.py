@@ -26,7 +26,7 @@ class KtnParams(C.Structure):
                 ("lp_dual_inherit", c_i32), ("profile", c_i32), ("purge_age", c_i32), ("purge_margin", c_f64),
                 ("purge_min_frac", c_f64), ("purge_min_rows", c_i64), ("lp_dense_after", c_i32), ("cut_cap_factor", c_f64), ("cut_cap_min", c_i64), ("lp_stag_factor", c_f64),
                 ("lp_ruiz_warm", c_i32), ("lp_tiled_nnz", c_i64), ("lp_near_check", c_i32), ("dedupe_eps", c_f64), ("polish_factor", c_f64), ("polish_max_var", c_i32), ("polish_max_iter", c_i32),
-                ("epi_shift", c_i32), ("obj_cert_tol", c_f64)]
+                ("epi_shift", c_i32), ("obj_cert_tol", c_f64), ("lp_mid_max_var", c_i32)]
 
 
 class KtnNlpDesc(C.Structure):

@@ -42,10 +42,12 @@ struct EcpBatch {
     int32_t* cut_prev;                                             // per row: previous cut of the same NL slot (-1): lists for the stall handler
     double* ax;                                                    // per row: scaled activity A^ xt of the last check
     double* x;                                                     // [ncols_total] out: solution (unscaled); in: ignored
+    double* xbest;                                                 // [ncols_total] scratch: best point of the certificate refinement
     double* res;                                                   // [nb * 8] out: status, ecp iterations, objective, cuts, pdhg iterations, max violation, lp rows, -
     // ---- parameters
     double f_tol, cut_coef_rng, tol_scale, tol_floor, tol_cap, gap_floor, gap_cap, stag_factor;
-    int iter_cap, lp_max_iter, check_every, near_chunk, ruiz_iters, power_passes, nmax, mmax;
+    double cert_tol;                 // obj_cert_tol: per-instance objective certificate (below); 0 = stop at the reference's rule alone
+    int iter_cap, lp_max_iter, check_every, near_chunk, ruiz_iters, power_passes, nmax, mmax, polish_max_iter;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
     int32_t* cut_prev = B.cut_prev + A.row0;
     double* axv = B.ax + A.row0;
     double* xg = B.x + c0;
+    double* xbest = B.xbest + c0;
 
     double* xs = sm;                   // x (scaled)
     double* x0s = xs + B.nmax;
@@ -172,13 +175,23 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
     long pdhg_total = 0;
     double last_maxviol = 1e300, objval = 0.0, om_keep = -1.0;
     bool allsat = false, overflow = false;
-    const double floor_p = B.tol_floor * B.f_tol;
+    // Objective certificate per instance (Engine::objective_certificate / kernels.hpp "objective certificate", round 4): at the
+    // point that meets the reference's stop rule the workgroup adds up  D = sum_i lambda_i * (signed residual of NL row i)  with
+    // lambda_i the LP duals summed over the cuts of row i -- the part of  f* - objective  the stop rule leaves open -- and while
+    // D exceeds half of cert_tol * max(1, |objective|) it keeps cutting at  f_eff = phi * f_tol  with the LP gap tolerance at a
+    // quarter of the target (passes not counted in the iteration number, at most polish_max_iter).  The point returned is the
+    // one with the smallest violation among those that satisfy the reference's rule.
+    double f_eff = B.f_tol, gap_cert = 1e300, best_viol = 1e300, best_obj = 0.0;
+    int passes = 0;
+    bool refining = false;
+  for (;;) {
+    const double floor_p = B.tol_floor * f_eff;
 
-    while (!allsat && iter < B.iter_cap) {
-        ++iter;
+    while (!allsat && (refining ? passes <= B.polish_max_iter : iter < B.iter_cap)) {
+        if (refining) ++passes; else ++iter;
         double tol_p = fmin(fmax(B.tol_scale * last_maxviol, floor_p), B.tol_cap);
-        if (m_nl == 0) tol_p = floor_p;
-        const double tol_g = fmin(fmax(tol_p, B.gap_floor), B.gap_cap);
+        if (m_nl == 0 || refining) tol_p = floor_p;
+        const double tol_g = fmin(fmin(fmax(tol_p, B.gap_floor), B.gap_cap), gap_cert);
 
         // ============================================================ column mirror of the current rows ================
         // counting sort by column, then every column's entries sorted by row (fixed summation order of A'y)
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
                 if (lane == 0) {
                     g += B.P.rconst[gr];
                     const double lb = B.P.lb[gr], ub = B.P.ub[gr];
-                    const bool sat = (g >= lb - B.f_tol) && (g <= ub + B.f_tol);       // NaN -> violated
+                    const bool sat = (g >= lb - f_eff) && (g <= ub + f_eff);           // NaN -> violated
                     icnt[i] = sat ? 0 : (int)(end - beg);
                     yts[i] = g;                                                         // keep g for the emit pass (m_nl <= mmax)
                     if (!sat) { double d = fmax(g - ub, lb - g); if (!(d == d)) d = __builtin_inf(); mv[0] = fmax(mv[0], d); }
@@ -622,6 +635,49 @@ __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
         const bool sat_now = V == 0;
         if (sat_now && tol_p > floor_p * (1.0 + 1e-12)) last_maxviol = 0.0;        // inexact-LP rule: re-solve at the floor tolerance
         else allsat = sat_now;
+        if (refining && mv[0] <= B.f_tol && mv[0] < best_viol) {                    // a candidate for the answer (uniform: mv is reduced)
+            best_viol = mv[0]; best_obj = objval;
+            for (int j = tid; j < nb; j += kEcpThreads) xbest[j] = xg[j];
+        }
+    }
+    // ---- certificate: refine, or done
+    if (!allsat && !refining) break;                                               // iteration cap
+    if (status != KTN_STATUS_NONE || !(B.cert_tol > 0.0) || m_nl == 0 || B.polish_max_iter <= 0) break;
+    if (refining && passes > B.polish_max_iter) break;
+    {
+        double d1[1] = {0.0};
+        for (int i = tid; i < m_nl; i += kEcpThreads) {
+            double lam = 0.0;
+            for (int r = last_cut[i]; r >= 0; r = cut_prev[r]) lam += fabs(yv[r]);
+            const int32_t gr = B.nl_rows[nl0 + i];
+            const double lb = B.P.lb[gr], ub = B.P.ub[gr], g = yts[i];
+            double v = -__builtin_inf();
+            if (isfinite(ub)) v = fmax(v, g - ub);
+            if (isfinite(lb)) v = fmax(v, lb - g);
+            if (v >= -10.0 * B.f_tol) d1[0] += lam * v;
+        }
+        ecp_reduce<1>(d1, 1, red, q);
+        const double D = (q[0] == q[0]) ? fmax(q[0], 0.0) : __builtin_inf();
+        const double target = B.cert_tol * fmax(1.0, fabs(objval));
+        __syncthreads();
+        if (allsat && D <= 0.5 * target) break;                                     // the reference's objective tolerance holds
+        if (!refining) {                                                            // the point that met the stop rule is the first candidate
+            refining = true;
+            best_viol = B.f_tol; best_obj = objval;                                 // (any later point that is strictly inside replaces it)
+            for (int j = tid; j < nb; j += kEcpThreads) xbest[j] = xg[j];
+        }
+        f_eff = fmin(fmax(0.25 * target / D, 0.05), 0.5) * B.f_tol;
+        gap_cert = 0.25 * target / (1.0 + 2.0 * fabs(objval));
+        allsat = false;
+        last_maxviol = 0.0;
+    }
+  }
+    if (refining) {                                                                 // the best point that satisfies the reference's rule
+        __syncthreads();
+        for (int j = tid; j < nb; j += kEcpThreads) xg[j] = xbest[j];
+        objval = best_obj;
+        allsat = true;
+        last_maxviol = best_viol;
     }
     if (status == KTN_STATUS_NONE) status = (iter >= B.iter_cap && !allsat) ? KTN_STATUS_USERLIMIT : (allsat ? KTN_STATUS_OPTIMAL : KTN_STATUS_USERLIMIT);
     if (tid == 0) {

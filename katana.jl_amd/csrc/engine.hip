@@ -27,6 +27,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "dense_lp.hpp"
+#include "mid_lp.hpp"
 #include "batch_lp.hpp"
 #include "batch_ecp.hpp"
 #include "prims.hpp"
@@ -299,6 +300,13 @@ struct Engine {
     int64_t lp_iter_budget = 0, dense_credit = 0, dense_run = 0;
     DBuf<int32_t> ds_W, ds_valid;
     DBuf<double> ds_dense, ds_out;
+    // exact mid-size LP (mid_lp.hpp): basis inverse, working set, x and multipliers persist across the ECP iterations
+    DBuf<double> md_Binv, md_hW, md_x, md_lam, md_u, md_d, md_r, md_pv, md_c;
+    int64_t mid_backoff = 0, mid_backoff_len = 0;      // after a failed exact solve the first-order method carries on alone for a while
+    DBuf<int32_t> md_W, md_pi, md_lost;
+    DBuf<MidState> md_st;
+    bool md_valid = false;
+    int64_t mid_credit = 0, mid_run = 0;
     DBuf<int32_t> d_longrows;
     // long COLUMNS of the mirror (a variable that every cut contains: min-max / epigraph-style models): found by find_long_cols
     // after the mirror is built; the column-side kernels then run in their vector form with a workgroup per long column
@@ -347,7 +355,7 @@ struct Engine {
     DBuf<int64_t> d_blklin, d_blknl;
     DBuf<int32_t> e_rptr, e_cptr, e_last, e_prev;
     DBuf<uint16_t> e_rcol, e_crow;
-    DBuf<double> e_ax, e_rval, e_rsval, e_lo, e_hi, e_y, e_dr, e_loh, e_hih, e_cval, e_csval, e_dc, e_ch, e_lh, e_uh, e_res;     // batch_ecp.hpp: the whole ECP loop of every instance in its own workgroup
+    DBuf<double> e_xbest, e_ax, e_rval, e_rsval, e_lo, e_hi, e_y, e_dr, e_loh, e_hih, e_cval, e_csval, e_dc, e_ch, e_lh, e_uh, e_res;     // batch_ecp.hpp: the whole ECP loop of every instance in its own workgroup
     bool lp_solve_blocks(double tol_p, double tol_g, double eta, LpResult* R, int64_t max_it);
     double smax_prev = 0.0;
     int64_t smax_rows = 0;
@@ -367,8 +375,12 @@ struct Engine {
     int polish_count = 0;
     double polish_phi = 1e-3;       // the refinement cuts rows beyond polish_phi * f_tol
     double cert_target = 0.0;       // > 0: certificate-driven refinement (kernels.hpp "objective certificate"), ends when met
+    double cert_gap = 0.0;          // relative LP gap tolerance of the refinement solves (a quarter of the objective target)
     DBuf<double> d_cert;
     double objective_certificate(int64_t id_offset = 0, bool raw = false);
+    double certificate_all_ranks();
+    double certificate_blocks(double* gap_tol);
+    DBuf<double> d_certblk;
     double best_viol = kInf, best_obj = 0.0;
     DBuf<double> d_xbest;
     // print_header / print_stats bookkeeping  src/model.jl:209-217,252-254,284-303
@@ -465,8 +477,10 @@ struct Engine {
     double* ipc_slot() const { return dist.ipc.data + ipc_off(); }
     void ipc_check() {
         if (dist.ipc.on && dist.ipc.h_err && *dist.ipc.h_err != 0) {
-            const int src = *dist.ipc.h_err - 1;
-            throw Error(KTN_E_HIP, "peer-buffer transport: rank " + std::to_string(dist.rank) + " timed out waiting for rank " + std::to_string(src));
+            const int code = *dist.ipc.h_err;           // 1 + r: rank r did not arrive in time; 101 + r: rank r reported its own failure
+            if (code > 100)
+                throw Error(KTN_E_HIP, "peer-buffer transport: rank " + std::to_string(code - 101) + " gave up (told rank " + std::to_string(dist.rank) + ")");
+            throw Error(KTN_E_HIP, "peer-buffer transport: rank " + std::to_string(dist.rank) + " timed out waiting for rank " + std::to_string(code - 1));
         }
     }
     // signal "my slot of this epoch is complete" to every rank and wait for theirs; returns the slot offset to read
@@ -602,7 +616,21 @@ struct Engine {
     void precompute_all(const double* d_x) {
         NlpDev P = nlp_view();
         SweepOut O = sweep_view();
-        LAUNCH_G(grp_sweep, k_sep_eval, m_ext, stream, P, d_allrows.p, m_ext, d_x, 0.0, 1, 0, O);
+        // many short rows: the R-rows-per-lane-group form of the sweep with the Jacobian store (same sums, same bits); the
+        // selection is the sweep's: once one row per group would make several times the resident wavefronts
+        const int64_t waves1 = m_ext * grp_sweep / 64, resident = (int64_t)num_cus * 32;
+        if (waves1 >= 16 * resident) {
+#define KTN_PRE_LAUNCH(G) hipLaunchKernelGGL((k_sep_sweep<G, 4, true>), dim3(ceil_div(ceil_div(m_ext, (int64_t)4) * G, kBlock)), dim3(kBlock), 0, stream, P, d_allrows.p, m_ext, d_x, 0.0, O)
+            switch (grp_sweep) {
+                case 8: KTN_PRE_LAUNCH(8); break;
+                case 16: KTN_PRE_LAUNCH(16); break;
+                case 32: KTN_PRE_LAUNCH(32); break;
+                default: KTN_PRE_LAUNCH(64); break;
+            }
+#undef KTN_PRE_LAUNCH
+        } else {
+            LAUNCH_G(grp_sweep, k_sep_eval, m_ext, stream, P, d_allrows.p, m_ext, d_x, 0.0, 1, 0, O);
+        }
         LAUNCH_1(k_tape_eval, (int64_t)d_taperows_all.n, stream, P, d_taperows_all.p, (int64_t)d_taperows_all.n, d_x, O);
         if (n_host > 0) host_eval(d_x);
         // cut constants / maxima of tape rows from the materialised Jacobian (flags unused here)
@@ -796,6 +824,7 @@ struct Engine {
     LpResult lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling = false);
     LpResult lp_solve_core(double tol_p, double tol_g, int mode, bool identity_scaling);
     bool lp_solve_dense(LpResult* R);
+    bool lp_solve_mid(LpResult* R);
     void pdhg_raw(const double* x0, const double* y0, double eta, double omega_, int64_t iters, double* x_out,
                   double* y_out);
 
@@ -1337,6 +1366,7 @@ void Engine::reset() {
     if (d_blkomega.n) d_blkomega.zero(stream);
     if (ds_valid.n) ds_valid.zero(stream);
     dense_credit = dense_run = 0;
+    md_valid = false; mid_credit = mid_run = 0; mid_backoff = mid_backoff_len = 0;
     if (glists) KTN_HIP(hipMemsetAsync(d_glast.p, 0xFF, d_glast.n * sizeof(int64_t), stream));
     last_sweep_cuts = 0;
     power_v.n = 0;
@@ -1561,6 +1591,14 @@ void Engine::purge_cuts() {
     lp_rowptr.n = (size_t)m_new + 1; lp_col.n = lp_val.n = (size_t)nnz_new;
     lp_lo.n = lp_hi.n = lp_y.n = d_age.n = d_cutprev.n = (size_t)m_new;
     if (ds_valid.n) ds_valid.zero(stream);          // row indices changed: the dense path's working set is void
+    if (md_valid) {                                 // the mid-size solver's working rows move with the compaction (dropped one: cold start)
+        md_lost.zero(stream);
+        hipLaunchKernelGGL(k_mid_remap, dim3((unsigned)ceil_div(n_lp, 256)), dim3(256), 0, stream, (int)n_lp, md_W.p, d_keep.p, d_newidx.p, md_lost.p);
+        int32_t lost = 0;
+        KTN_HIP(hipMemcpyAsync(&lost, md_lost.p, 4, hipMemcpyDeviceToHost, stream));
+        sync();
+        if (lost) md_valid = false;
+    }
     smax_rows = 0;
     stats["purged_rows"] += (double)(m - m_new);
     purged_total += m - m_new;
@@ -1843,7 +1881,9 @@ bool Engine::optimize_blocks_device(int cap_mul) {
     B.loh = e_loh.p; B.hih = e_hih.p;
     B.cptr = e_cptr.p; B.crow = e_crow.p; B.cval = e_cval.p; B.csval = e_csval.p;
     B.dc = e_dc.p; B.ch = e_ch.p; B.lh = e_lh.p; B.uh = e_uh.p;
-    B.last_cut = e_last.p; B.cut_prev = e_prev.p; B.ax = e_ax.p; B.x = lp_x.p; B.res = e_res.p;
+    e_xbest.resize((size_t)n_lp + 1, stream);
+    B.last_cut = e_last.p; B.cut_prev = e_prev.p; B.ax = e_ax.p; B.x = lp_x.p; B.xbest = e_xbest.p; B.res = e_res.p;
+    B.cert_tol = prm.obj_cert_tol; B.polish_max_iter = prm.polish_max_iter;
     B.f_tol = prm.f_tol; B.cut_coef_rng = prm.cut_coef_rng; B.tol_scale = prm.lp_tol_scale; B.tol_floor = prm.lp_tol_floor;
     B.tol_cap = prm.lp_tol_cap; B.gap_floor = prm.lp_gap_floor; B.gap_cap = prm.lp_gap_cap; B.stag_factor = prm.lp_stag_factor;
     B.iter_cap = prm.iter_cap; B.lp_max_iter = prm.lp_max_iter; B.check_every = std::max(2, prm.lp_check_every);
@@ -2085,6 +2125,40 @@ void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double si
 LpResult Engine::lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling) {
     const bool dense_ok = mode == 0 && !identity_scaling && !row_sharded() && prm.lp_dense_after != 0 && n_lp >= 1 && n_lp <= kDenseMaxN &&
                           M * n_lp <= 8000000;
+    // ... and LPs of 33 .. lp_mid_max_var columns by the exact mid-size solver (mid_lp.hpp), under the same hand-over rule
+    const bool mid_ok = mode == 0 && !identity_scaling && !row_sharded() && prm.lp_dense_after != 0 && n_lp > kDenseMaxN &&
+                        n_lp <= std::min<int64_t>(prm.lp_mid_max_var, kMidMaxN) && n_blocks == 0 && M < ((int64_t)1 << 29);
+    if (mid_ok && mid_backoff > 0) {
+        --mid_backoff;                                   // (a recent exact solve failed: cold starts cost ~n pivots each, do not repeat them at once)
+    } else if (mid_ok) {
+        auto failed = [&]() {
+            stats["mid_lp_fallbacks"] += 1.0;
+            mid_credit = 0;
+            mid_backoff_len = std::min<int64_t>(2 * std::max<int64_t>(mid_backoff_len, 4), 256);
+            mid_backoff = mid_backoff_len;
+        };
+        if (prm.lp_dense_after < 0 || mid_credit > 0) {
+            if (mid_credit > 0) --mid_credit;
+            LpResult R;
+            if (lp_solve_mid(&R)) return R;
+            failed();
+            return lp_solve_core(tol_p, tol_g, mode, identity_scaling);
+        }
+        lp_iter_budget = prm.lp_dense_after;
+        LpResult R = lp_solve_core(tol_p, tol_g, mode, identity_scaling);
+        lp_iter_budget = 0;
+        if (R.status != KTN_STATUS_USERLIMIT) return R;
+        stats["lp_stalls"] += 1.0;
+        LpResult D;
+        if (lp_solve_mid(&D)) {
+            mid_run = std::min<int64_t>(2 * std::max<int64_t>(mid_run, 1), 1 << 20);
+            mid_credit = mid_run;
+            mid_backoff_len = 0;
+            return D;
+        }
+        failed();
+        return lp_solve_core(tol_p, tol_g, mode, identity_scaling);
+    }
     if (!dense_ok) return lp_solve_core(tol_p, tol_g, mode, identity_scaling);
     if (prm.lp_dense_after < 0 || dense_credit > 0) {
         if (dense_credit > 0) --dense_credit;
@@ -2155,6 +2229,118 @@ bool Engine::lp_solve_dense(LpResult* R) {
         return true;
     }
     return false;
+}
+
+// Exact solve of a mid-size LP (mid_lp.hpp): batches of pivots enqueued without a host synchronisation, the device-resident
+// state read back once per batch.  Returns false when the solver gives up (an artificial side of a free variable is still
+// needed, pivot limit, a basis inverse that a cold restart does not repair): the caller then runs the first-order method.
+bool Engine::lp_solve_mid(LpResult* R) {
+    auto t0 = std::chrono::steady_clock::now();
+    const int n = (int)n_lp;
+    const int64_t m = M;
+    if (md_W.n != (size_t)n) {
+        md_Binv.resize((size_t)n * n, stream);
+        md_W.resize(n, stream); md_hW.resize(n, stream); md_x.resize(n, stream); md_lam.resize(n, stream);
+        md_u.resize(n, stream); md_d.resize(n, stream); md_r.resize(n, stream); md_c.resize(n, stream);
+        md_pv.resize(kMidPriceBlocks, stream); md_pi.resize(kMidPriceBlocks, stream); md_st.resize(1, stream); md_lost.resize(1, stream);
+        md_valid = false;
+    }
+    lp_y.resize((size_t)std::max<int64_t>(m, 1), stream);
+    lp_y.n = (size_t)m;
+    MidLpIO P;
+    P.n = n; P.m = m; P.rowptr = lp_rowptr.p; P.col = lp_col.p; P.val = lp_val.p; P.lo = lp_lo.p; P.hi = lp_hi.p;
+    P.l = lp_l.p; P.u = lp_u.p; P.c = lp_c.p; P.sgn = (sense == KTN_MAX) ? -1.0 : 1.0;
+    P.Binv = md_Binv.p; P.W = md_W.p; P.hW = md_hW.p; P.x = md_x.p; P.lam = md_lam.p; P.uvec = md_u.p; P.dvec = md_d.p; P.rvec = md_r.p;
+    P.part_val = md_pv.p; P.part_idx = md_pi.p; P.st = md_st.p; P.ctil = md_c.p;
+    P.tol = 1e-9;
+    // (a cold start from the bound vertex of a cutting-plane LP that the first-order method has already grown to a few thousand
+    //  rows takes tens of pivots per column -- every variable leaves its box corner, many of them more than once; the warm
+    //  re-solves that follow take tens to hundreds in total)
+    P.max_pivots = 5000 + 200 * n + (int)std::min<int64_t>(20 * m, 4000000);
+    const unsigned g_nn = (unsigned)ceil_div((int64_t)n * n, 256), g_n = (unsigned)ceil_div(n, 256);
+    auto refine = [&]() {                               // x = B^-1 h_W + one step of iterative refinement; lambda = -B^-T c
+        hipLaunchKernelGGL(k_mid_resid, dim3(g_n), dim3(256), 0, stream, P, 0);
+        hipLaunchKernelGGL(k_mid_apply, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, P, 0);
+        hipLaunchKernelGGL(k_mid_resid, dim3(g_n), dim3(256), 0, stream, P, 1);
+        hipLaunchKernelGGL(k_mid_apply, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, P, 1);
+        hipLaunchKernelGGL(k_mid_resid, dim3(g_n), dim3(256), 0, stream, P, 1);
+        hipLaunchKernelGGL(k_mid_resid_norm, dim3(1), dim3(256), 0, stream, P, 1);
+        hipLaunchKernelGGL(k_mid_lambda, dim3(g_n), dim3(256), 0, stream, P);
+    };
+    MidState hs;
+    int total_pivots = 0, status = 4;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!md_valid) {
+            hipLaunchKernelGGL(k_mid_init, dim3(g_nn), dim3(256), 0, stream, P);
+            stats["mid_lp_cold_starts"] += 1.0;
+        } else {
+            hipLaunchKernelGGL(k_mid_rearm, dim3(1), dim3(1), 0, stream, md_st.p);
+        }
+        int refined_at = -1, refinements = 0;
+        bool bad_inverse = false;
+        status = 4;
+        for (;;) {
+            for (int b = 0; b < 8; ++b) {
+                hipLaunchKernelGGL(k_mid_price, dim3(kMidPriceBlocks), dim3(256), 0, stream, P);
+                hipLaunchKernelGGL(k_mid_select, dim3(1), dim3(256), 0, stream, P);
+                hipLaunchKernelGGL(k_mid_u, dim3(g_n), dim3(256), 0, stream, P);
+                hipLaunchKernelGGL(k_mid_ratio, dim3(1), dim3(256), 0, stream, P);
+                hipLaunchKernelGGL(k_mid_rank1, dim3(g_nn), dim3(256), 0, stream, P);
+            }
+            check_launch();
+            KTN_HIP(hipMemcpyAsync(&hs, md_st.p, sizeof(hs), hipMemcpyDeviceToHost, stream));
+            sync();
+            if (hs.status == 0) continue;
+            if (hs.status == 1) {
+                if (refined_at == hs.pivots) {          // the confirming price after the refinement found nothing either
+                    if (!(hs.resid <= 1e-7 * hs.scale)) { bad_inverse = true; break; }
+                    status = 0;
+                    break;
+                }
+                if (++refinements > 50) break;
+                refine();
+                refined_at = hs.pivots;
+                continue;
+            }
+            status = hs.status;                          // 3 infeasible, 4 failed
+            break;
+        }
+        total_pivots += hs.pivots;
+        if (status == 0 || status == 3) break;
+        md_valid = false;                                // failed on a warm start (or a decayed inverse): once more from the bound vertex
+        if (!bad_inverse && attempt == 0 && hs.pivots >= P.max_pivots) break;      // (a pivot limit is not repaired by a restart)
+    }
+    stats["mid_lp_solves"] += 1.0;
+    stats["mid_lp_pivots"] += (double)total_pivots;
+    stats["lp_solves"] += 1.0;
+    bool ok = false;
+    if (status == 0) {
+        KTN_HIP(hipMemsetAsync(lp_y.p, 0, (size_t)std::max<int64_t>(m, 1) * sizeof(double), stream));
+        hipLaunchKernelGGL(k_mid_final, dim3(1), dim3(256), 0, stream, P, lp_y.p);
+        KTN_HIP(hipMemcpyAsync(lp_x.p, md_x.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        KTN_HIP(hipMemcpyAsync(&hs, md_st.p, sizeof(hs), hipMemcpyDeviceToHost, stream));
+        check_launch();
+        sync();
+        if (hs.art_left == 0) {
+            R->status = KTN_STATUS_OPTIMAL;
+            R->iters = total_pivots;
+            R->pobj = R->dobj = hs.obj;
+            R->row_viol = 0.0; R->gap = 0.0;
+            R->exact = true;
+            objval = P.sgn * hs.obj + c0;
+            md_valid = true;
+            ok = true;
+        } else {
+            md_valid = false;
+        }
+    } else if (status == 3) {
+        R->status = KTN_STATUS_INFEASIBLE;
+        R->iters = total_pivots;
+        md_valid = false;
+        ok = true;
+    }
+    stats["lp_time_s"] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return ok;
 }
 
 LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identity_scaling) {
@@ -2570,12 +2756,28 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         r_prev = r;
         if (restart) {
             const double dx = std::sqrt(dx0sq), dy = std::sqrt(dy0sq);
+            if (dbg_lp) std::fprintf(stderr, "[lp restart] it %lld k %lld decayed %d dx %.3e dy %.3e |xt| %.3e |yt| %.3e om %.4g\n", (long long)it, (long long)k, (int)decayed, dx, dy, std::sqrt(xt2), std::sqrt(yt2), om);
             // guarded primal-weight update (oracle/pdlp_mirror.py solve_lp_halpern)
             static const int om_art = std::getenv("KTN_OMEGA_ART") ? std::atoi(std::getenv("KTN_OMEGA_ART")) : 1;
+            // Unearned restarts carry little information about the weight (round 4).  The update reads the ratio
+            // of the two movements since the last restart.  A solve's first restarts come "by the clock" (k >= 0.36 it: at the
+            // first check of every solve, after 32 iterations), whether or not the residual has moved.  After a warm start whose
+            // primal part is already converged (cfg2 seed 92: row violation 2e-7, dual objective 3e-4 away) x moves by 1e-6 of
+            // its norm in such a period -- the size of the tolerance -- and the ratio of that movement to the dual's sent the
+            // weight 603 -> 140 -> 13.8 -> 0.77 -> 0.16 in four restarts that had not reduced the residual at all; the solve then
+            // needed 44 000 iterations to earn it back.  (Tried first, and harmful: skipping the update below a relative movement
+            // of 10-100 gap tolerances -- any such floor also silences the early, loose solves, whose movements are small AND
+            // informative: cfg3 13 -> 36-85 cutting-plane rounds, profiles/r04_omega_ab.txt.)  Instead the weight of the new
+            // ratio in the geometric mean grows with the length of the period it was measured over: theta = 0.5 min(1, k / K)
+            // for a restart the residual did not earn (K = KTN_OMEGA_ART_K, 0 = the plain 0.5), 0.5 for an earned one.
+            static const double om_art_k = std::getenv("KTN_OMEGA_ART_K") ? std::atof(std::getenv("KTN_OMEGA_ART_K")) : 256.0;
+            static const double om_art_clamp = std::getenv("KTN_OMEGA_ART_CLAMP") ? std::atof(std::getenv("KTN_OMEGA_ART_CLAMP")) : 0.0;
             if ((om_art || decayed) && dx > 1e-8 * (1.0 + std::sqrt(xt2)) && dy > 1e-8 * (1.0 + std::sqrt(yt2))) {
                 static const double om_clamp = std::getenv("KTN_OMEGA_CLAMP") ? std::atof(std::getenv("KTN_OMEGA_CLAMP")) : 0.0;
                 const double om_old = om;
-                om = std::exp(0.5 * std::log(dy / dx) + 0.5 * std::log(om));
+                const double theta = (!decayed && om_art_k > 0.0) ? 0.5 * std::min(1.0, (double)k / om_art_k) : 0.5;
+                om = std::exp(theta * std::log(dy / dx) + (1.0 - theta) * std::log(om));
+                if (!decayed && om_art_clamp > 1.0) om = std::min(std::max(om, om_old / om_art_clamp), om_old * om_art_clamp);
                 static const double om_clamp_dn = std::getenv("KTN_OMEGA_CLAMP_DOWN") ? std::atof(std::getenv("KTN_OMEGA_CLAMP_DOWN")) : 0.0;
                 if (om_clamp > 1.0) om = std::min(std::max(om, om_old / om_clamp), om_old * om_clamp);
                 if (om_clamp_dn > 1.0) om = std::max(om, om_old / om_clamp_dn);
@@ -2822,6 +3024,7 @@ void Engine::step(int32_t* done) {
     global_sweep(lp_x.p, prm.f_tol, &nviol, &mv, &nonfin);               // model.jl:268-283
     if (nonfin) { status = KTN_STATUS_ERROR; return; }
     last_maxviol = mv;
+    stats["last_maxviol"] = mv; stats["last_nviol"] = (double)nviol;
     const bool sat_now = (nviol == 0);
     // inexact-LP rule (DESIGN.md "LP tolerance schedule"): all rows satisfied only counts once
     // the LP itself was solved to the floor tolerance -- by request, or because the last check of a looser solve
@@ -2857,16 +3060,21 @@ void Engine::step(int32_t* done) {
     // Terminal refinement of small problems: the reference's simplex vertices end Kelley's method with the last
     // violation far below f_tol (its tests ask the objective to 1e-6 / 1e-7); a first-order LP ends AT f_tol.
     bool refine = false;
-    if (allsat && !eps_stop && !polish_done && !sharded_rows && !row_sharded() && prm.polish_max_iter > 0 && m_nl > 0) {
-        if (n_lp <= prm.polish_max_var) {
+    // (row-sharded LP: every rank holds the cut lists of its own NL rows, so the certificate is the all-reduced sum of the ranks'
+    //  shares and every decision below is taken from all-reduced numbers: all ranks refine, or none)
+    if (allsat && !eps_stop && !polish_done && !sharded_rows && prm.polish_max_iter > 0 && m_nl_global > 0) {
+        if (n_lp <= prm.polish_max_var && !row_sharded()) {
             refine = prm.polish_factor > 0.0 && prm.polish_factor < 1.0;
             polish_phi = prm.polish_factor;
             cert_target = 0.0;
-        } else if (prm.obj_cert_tol > 0.0 && lists_ok() && n_blocks == 0) {
+        } else if (prm.obj_cert_tol > 0.0 && lists_ok()) {
             // Larger problems: refine only while the multiplier-weighted residual of the NL rows (the part of  f* - objective  the
-            // stop rule leaves open; the LP's own accuracy is its gap tolerance) exceeds half the objective tolerance
-            const double target = prm.obj_cert_tol * std::max(1.0, std::fabs(objval));
-            const double D = objective_certificate();
+            // stop rule leaves open; the LP's own accuracy is its gap tolerance) exceeds half the objective tolerance.
+            // (A fused batch -- ktn_set_blocks -- owes the tolerance to EVERY instance: D is then the largest per-instance
+            //  certificate in units of that instance's target, and the target is 1.)
+            const double target = n_blocks > 0 ? 1.0 : prm.obj_cert_tol * std::max(1.0, std::fabs(objval));
+            cert_gap = 0.25 * target / (1.0 + 2.0 * std::fabs(objval));
+            const double D = n_blocks > 0 ? certificate_blocks(&cert_gap) : certificate_all_ranks();
             stats["cert_evals"] += 1.0;
             stats["cert_last"] = D;
             if (D > 0.5 * target) {
@@ -2916,7 +3124,7 @@ void Engine::polish_step(int32_t* done) {
     *done = 0;
     if (polish_count == 0) {
         // first pass: measure (and cut at) the point that met the stop rule
-        sweep(lp_x.p, f_eff, &nviol, &mv, &nonfin);
+        global_sweep(lp_x.p, f_eff, &nviol, &mv, &nonfin);
         if (nonfin) { status = KTN_STATUS_ERROR; polishing = false; *done = 1; return; }
         consider(mv);
         polish_count = 1;
@@ -2929,15 +3137,16 @@ void Engine::polish_step(int32_t* done) {
     const double tol_p = prm.lp_tol_floor * f_eff;
     // gap tolerance of a refinement solve: scaled with the cut tolerance (small problems); in certificate mode a quarter of the
     // objective tolerance, as a relative gap
-    const double tol_g = cert_target > 0.0 ? std::min(std::min(std::max(tol_p, prm.lp_gap_floor), prm.lp_gap_cap), 0.25 * cert_target / (1.0 + 2.0 * std::fabs(objval)))
+    const double tol_g = cert_target > 0.0 ? std::min(std::min(std::max(tol_p, prm.lp_gap_floor), prm.lp_gap_cap), cert_gap)
                                            : std::max(prm.lp_gap_floor * polish_phi, 1e-12);
     LpResult R = lp_solve(tol_p, tol_g, 0);
     if (R.status != KTN_STATUS_OPTIMAL) { finish(); return; }            // keep the point that met the stop rule
-    sweep(lp_x.p, f_eff, &nviol, &mv, &nonfin);
+    global_sweep(lp_x.p, f_eff, &nviol, &mv, &nonfin);
     if (nonfin) { finish(); return; }
     consider(mv);
     if (cert_target > 0.0 && mv <= prm.f_tol) {                          // certificate mode: done as soon as the bound holds
-        const double D = objective_certificate();
+        double gap_now = 0.0;
+        const double D = n_blocks > 0 ? certificate_blocks(&gap_now) : certificate_all_ranks();
         stats["cert_evals"] += 1.0;
         stats["cert_last"] = D;
         if (D <= 0.5 * cert_target) { finish(); return; }
@@ -2959,6 +3168,37 @@ double Engine::objective_certificate(int64_t id_offset, bool raw) {
     KTN_HIP(hipMemcpyAsync(&D, d_scal.p, sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
     if (raw) return D;
+    return (D == D) ? std::max(D, 0.0) : kInf;
+}
+
+// Fused batch: the largest per-instance certificate over that instance's own target (k_cert_blocks); *gap_tol = a quarter of the
+// smallest per-instance (target / (1 + 2 |objective|)): the relative gap the refinement's LP solves are asked for
+double Engine::certificate_blocks(double* gap_tol) {
+    if (m_nl <= 0 || n_blocks <= 0) return 0.0;
+    d_cert.resize((size_t)m_nl, stream);
+    LAUNCH_1(k_cert_nl, m_nl, stream, m_nl, d_nlrows.p, list_heads(), d_cutprev.p, lp_y.p, d_g.p, d_lb.p, d_ub.p, prm.f_tol, d_cert.p);
+    d_certblk.resize((size_t)(2 * n_blocks), stream);
+    hipLaunchKernelGGL(k_cert_blocks, dim3((unsigned)n_blocks), dim3(kBlock), 0, stream, m_nl, d_nlrows.p, d_rowptr.p, d_col.p, d_cert.p,
+                       d_blkcol.p, n_blocks, lp_c.p, lp_x.p, prm.obj_cert_tol, d_certblk.p);
+    check_launch();
+    std::vector<double> h = d_certblk.to_host(stream);
+    double worst = 0.0, gap = kInf;
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        const double r = h[(size_t)b];
+        worst = (r == r) ? std::max(worst, r) : kInf;
+        gap = std::min(gap, h[(size_t)(n_blocks + b)]);
+    }
+    if (gap_tol) *gap_tol = 0.25 * gap;
+    return worst;
+}
+
+// The certificate of a solve whose NL rows (and their cut lists) are spread over the ranks of a row-sharded LP: the signed shares
+// add up, the sum is clamped -- every rank gets the same number
+double Engine::certificate_all_ranks() {
+    if (!row_sharded()) return objective_certificate();
+    double D = objective_certificate(0, true);
+    if (!(D == D)) D = kInf;
+    allreduce_host(&D, 1, 0);
     return (D == D) ? std::max(D, 0.0) : kInf;
 }
 
@@ -3034,6 +3274,7 @@ void ktn_default_params(ktn_params* p) {
     p->polish_factor = 1e-3; p->polish_max_var = 32; p->polish_max_iter = 30;
     p->epi_shift = 1;
     p->obj_cert_tol = 1e-6;
+    p->lp_mid_max_var = 512;
 }
 
 int ktn_create(const ktn_params* p, ktn_handle* out) {
@@ -3325,6 +3566,7 @@ int ktn_lp_truncate(ktn_handle h, int64_t nrows) {
         e->scal_rows = std::min(e->scal_rows, nrows);
         e->sharded_rows = true;
         if (e->ds_valid.n) e->ds_valid.zero(e->stream);
+        e->md_valid = false;
         e->lp_rowptr.n = (size_t)nrows + 1; e->lp_col.n = e->lp_val.n = (size_t)base;
         e->lp_lo.n = e->lp_hi.n = e->lp_y.n = (size_t)nrows;
         if (e->d_age.n > (size_t)nrows) e->d_age.n = (size_t)nrows;

@@ -218,7 +218,9 @@ __global__ __launch_bounds__(kBlock) void k_sep_eval(NlpDev P, const int32_t* __
 // wavefront has four dependent memory round trips and 64 entries to show for them, and the kernel is latency-bound at
 // 4 % of the HBM peak; here the same four round trips serve R times as many entries.  Same arithmetic and the same
 // summation order per row as k_sep_eval (lane-strided partial sums, xor-butterfly), hence the same bits.
-template <int G, int R>
+// MAT = true is the literal precompute! (src/separators.jl:111-116) in the same form: the Jacobian values are stored, the
+// isconstrsat tail is left out (round 4: ktn_sep_precompute on 1e6 rows of 32 entries ran one row per group, 1.86 ms).
+template <int G, int R, bool MAT = false>
 __global__ __launch_bounds__(kBlock) void k_sep_sweep(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
                                                       const double* __restrict__ x, double f_tol, SweepOut O) {
     const int64_t s0 = (((int64_t)blockIdx.x * kBlock + threadIdx.x) / G) * R;
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(kBlock) void k_sep_sweep(NlpDev P, const int32_t* _
                 acc_dot[j] += xv[j] * der;
                 mx[j] = nanmax(mx[j], der);
                 nf[j] |= !isfinite(der);
+                if (MAT) O.jac[beg[j] + off] = der;
             }
         }
     }
@@ -292,19 +295,21 @@ __global__ __launch_bounds__(kBlock) void k_sep_sweep(NlpDev P, const int32_t* _
             O.bconst[rr] = g - acc_dot[j];
             O.maxc[rr] = m;
             O.nonfin[rr] = nf[j];
-            const double lb = P.lb[rr], ub = P.ub[rr];
-            const bool sat = (g >= lb - f_tol) && (g <= ub + f_tol);   // separators.jl:120 (NaN -> violated)
-            O.flag[s0 + j] = sat ? 0 : 1;
-            O.cnt[s0 + j] = sat ? 0 : len[j];
-            if (!sat) {
-                double v = fmax(g - ub, lb - g);
-                if (v != v) v = __builtin_inf();
-                viol = fmax(viol, v);
-                if (nf[j]) { if (*O.any_nonfin == 0) atomicOr(O.any_nonfin, 1); };
+            if (!MAT) {
+                const double lb = P.lb[rr], ub = P.ub[rr];
+                const bool sat = (g >= lb - f_tol) && (g <= ub + f_tol);   // separators.jl:120 (NaN -> violated)
+                O.flag[s0 + j] = sat ? 0 : 1;
+                O.cnt[s0 + j] = sat ? 0 : len[j];
+                if (!sat) {
+                    double v = fmax(g - ub, lb - g);
+                    if (v != v) v = __builtin_inf();
+                    viol = fmax(viol, v);
+                    if (nf[j]) { if (*O.any_nonfin == 0) atomicOr(O.any_nonfin, 1); };
+                }
             }
         }
     }
-    block_max_nonneg(O.maxviol, viol);
+    if (!MAT) block_max_nonneg(O.maxviol, viol);
 }
 
 // ---- column-blocked evaluation for LONG rows (HBM-resident Jacobians) ------------------
@@ -1397,14 +1402,29 @@ __device__ __forceinline__ double ipc_load(const double* p) {
 }
 __global__ __launch_bounds__(64) void k_ipc_barrier(IpcPeers P, int rank, int world, unsigned long long epoch, long long timeout_ticks,
                                                     int* __restrict__ err) {
+    // A failure is STICKY and FAST: once *err is set (a peer did not arrive in time, or a peer said it failed) every later
+    // barrier of this rank returns at once instead of spinning the full timeout again -- the host only looks at *err at the next
+    // KKT check, up to lp_check_every barriers later -- and tells the peers by writing the poison epoch into their flag words,
+    // so that they fail within one spin too instead of waiting for a rank that has given up.
+    constexpr unsigned long long kPoison = ~0ULL;
     const int t = threadIdx.x;
     if (t >= world) return;
+    volatile int* verr = err;
+    if (*verr != 0) {
+        if (t != rank) __hip_atomic_store(P.flags[t] + rank, kPoison, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     __hip_atomic_store(P.flags[t] + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);       // "my slot of this epoch is complete"
     const long long t0 = (long long)wall_clock64();
-    while (__hip_atomic_load(P.flags[rank] + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-        if ((long long)wall_clock64() - t0 > timeout_ticks) { *err = 1 + t; break; }
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(P.flags[rank] + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (v == kPoison) { *verr = 101 + t; break; }                                  // rank t gave up
+        if (v >= epoch) break;
+        if ((long long)wall_clock64() - t0 > timeout_ticks) { *verr = 1 + t; break; }  // rank t did not arrive
+        if (*verr != 0) break;                                                         // another lane of this barrier already failed
         __builtin_amdgcn_s_sleep(4);
     }
+    if (*verr != 0 && t != rank) __hip_atomic_store(P.flags[t] + rank, kPoison, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // out = sum (OP 0) or max (OP 1) over the ranks of their slot, in rank order
 template <int OP>
@@ -2276,6 +2296,38 @@ __global__ __launch_bounds__(kBlock) void k_cert_nl(int64_t m_nl, const int32_t*
     if (isfinite(ub[i])) v = fmax(v, g[i] - ub[i]);
     if (isfinite(lb[i])) v = fmax(v, lb[i] - g[i]);
     out[s] = (v >= -10.0 * f_tol) ? lam * v : 0.0;
+}
+// Per-BLOCK certificate of a fused batch (ktn_set_blocks: independent instances side by side, one objective tolerance EACH):
+// workgroup b adds up the shares of the NL slots whose row lives in block b's columns (fixed order: deterministic) and the
+// block's own objective c_b'x_b, and writes  out[b] = D_b / target_b  (target_b = tol * max(1, |obj_b|))  and
+// out[nb + b] = target_b / (1 + 2 |obj_b|)  (the relative LP gap a quarter of which the refinement solves ask for).
+__global__ __launch_bounds__(kBlock) void k_cert_blocks(int64_t m_nl, const int32_t* __restrict__ nl_rows, const int64_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, const double* __restrict__ cert,
+                                                        const int64_t* __restrict__ blk_col, int64_t nb, const double* __restrict__ c,
+                                                        const double* __restrict__ x, double tol, double* __restrict__ out) {
+    __shared__ double sh[kBlock];
+    const int64_t b = blockIdx.x;
+    const int64_t c0 = blk_col[b], c1 = blk_col[b + 1];
+    double d = 0.0, o = 0.0;
+    for (int64_t s = threadIdx.x; s < m_nl; s += kBlock) {
+        const int32_t r = nl_rows[s];
+        const int64_t e = rowptr[r];
+        if (rowptr[r + 1] > e) { const int32_t cc = col[e]; if (cc >= c0 && cc < c1) d += cert[s]; }
+    }
+    for (int64_t j = c0 + threadIdx.x; j < c1; j += kBlock) o += c[j] * x[j];
+    sh[threadIdx.x] = d;
+    __syncthreads();
+    for (int k = kBlock / 2; k > 0; k >>= 1) { if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k]; __syncthreads(); }
+    const double D = sh[0];
+    __syncthreads();
+    sh[threadIdx.x] = o;
+    __syncthreads();
+    for (int k = kBlock / 2; k > 0; k >>= 1) { if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        const double ob = fabs(sh[0]), target = tol * fmax(1.0, ob);
+        out[b] = (D == D) ? fmax(D, 0.0) / target : __builtin_inf();
+        out[nb + b] = target / (1.0 + 2.0 * ob);
+    }
 }
 // partials[b] = sum over the block's grid-stride share of a_i
 __global__ __launch_bounds__(kBlock) void k_sum_partial(int64_t n, const double* __restrict__ a, double* __restrict__ partials) {

@@ -106,13 +106,28 @@ def atom_value_deriv(kind, p0, p1, xv):
 
 def make_instance(n, m_nl, k, family="explog", seed=0, m_lin=None, lin_nnz=8, B=10.0,
                   active_frac=0.05, objective="linear", vertex=True, lin_active_frac=0.3,
-                  pivot_boost=True, shared_column=False):
-    """`shared_column` (or a family name ending in "+t"): one more variable t that EVERY nonlinear row contains,
+                  pivot_boost=True, shared_column=False, bound_frac=None):
+    """`bound_frac` is the *degeneracy dial*: the fraction of the non-pivot variables that is pinned on a bound with a
+    positive multiplier.  1.0 (default with `vertex=True`) is the non-degenerate vertex family; 0.0 is SURVEY.md section
+    8d's smooth-face generator itself (same as `vertex=False`: no variable pinned, every linear row slack, c = -sum lambda
+    grad g); values in between keep the active linear rows and the pivot matching and leave the un-pinned variables inside
+    the box with no bound multiplier, so the optimum lies on a curved face of dimension ~ (1 - bound_frac) * #non-pivot
+    variables: xhat stays a KKT point (the planted objective stays exact) but need no longer be the only minimiser, and
+    Kelley's method no longer has a vertex to lock on to.  `pivot_boost=False` additionally drops the conditioning help
+    (pivot entries as random as the others).  The random stream is that of the previous generator when bound_frac is 1.
+
+    `shared_column` (or a family name ending in "+t"): one more variable t that EVERY nonlinear row contains,
     g_i(x) - t <= r_i - that (the shape of min-max and epigraph models: minimise t subject to g_i(x) <= t).  Every cut then
     has an entry in t's column, which grows by up to m_nl entries per sweep -- the LP's long-column case.  t sits on its
     lower bound that with multiplier 1 and cost sum(lambda) + 1, so the planted point stays a non-degenerate KKT vertex."""
     if family.endswith("+t"):
         family, shared_column = family[:-2], True
+    if bound_frac is None:
+        bound_frac = 1.0 if vertex else 0.0
+    if not 0.0 <= bound_frac <= 1.0:
+        raise ValueError("bound_frac must lie in [0, 1]")
+    if bound_frac == 0.0:
+        vertex = False
     rng = np.random.default_rng(seed)
     m_lin = n // 2 if m_lin is None else m_lin
     lin_nnz = min(lin_nnz, n)
@@ -199,6 +214,8 @@ def make_instance(n, m_nl, k, family="explog", seed=0, m_lin=None, lin_nnz=8, B=
     c = -np.bincount(ncol, weights=(lam[nrow] * der), minlength=n)
     if vertex:
         at_bound = ~used
+        if bound_frac < 1.0:
+            at_bound &= rng.random(n) < bound_frac
         lower = at_bound & (rng.random(n) < 0.5)
         upper = at_bound & ~lower
         l_var[lower] = xhat[lower]
@@ -255,7 +272,7 @@ def make_instance(n, m_nl, k, family="explog", seed=0, m_lin=None, lin_nnz=8, B=
         xhat=xhat, opt_obj=opt, m_lin=m_lin, m_nl=m_nl,
         meta=dict(n=n, m_nl=m_nl, k=k, family=family, seed=seed, m_lin=m_lin, lin_nnz=lin_nnz, B=B,
                   active_frac=active_frac, objective=objective, n_active=int(active.sum()),
-                  vertex=bool(vertex), n_lin_active=int(lin_active.sum()), shared_column=bool(shared_column),
+                  vertex=bool(vertex), bound_frac=float(bound_frac), pivot_boost=bool(pivot_boost), n_lin_active=int(lin_active.sum()), shared_column=bool(shared_column),
                   # planted multipliers: an x with g_i(x) <= eps on the NL rows, a_r'x <= b_r + delta on the linear rows and the
                   # bounds met exactly has  c'x >= c'xhat - eps * lam_sum - delta * mu_sum  (Lagrangian bound at xhat)
                   lam_sum=float(lam.sum()), mu_sum=float(mu.sum())))
@@ -307,3 +324,52 @@ def fuse_instances(insts):
                   obj_ptr=np.concatenate([[0], np.cumsum([len(i.obj_col) for i in insts])]).astype(np.int64)))
     assert all(i.sense == fused.sense for i in insts)
     return fused, offs
+
+
+def make_lp(n, m, seed=0, nnz_row=8, B=10.0, active_frac=0.3, degenerate_frac=0.0, bad_scale_decades=0.0, free_frac=0.0):
+    """A random sparse LP with a planted primal-dual optimal pair, in the layout of `make_instance` (every row a separable row
+    of LIN atoms, no nonlinear row): the LP-only battery of tests/test_gpu_lp.py (engine LP against HiGHS).
+
+        min c'x   s.t.  a_r'x <= b_r (m rows, nnz_row entries each),   l <= x <= u
+
+    A fraction `active_frac` of the rows is tight at xhat and carries a multiplier; `degenerate_frac` more rows are tight WITHOUT a
+    multiplier (a primal-degenerate vertex: more tight constraints than the vertex needs); every variable that is in no
+    multiplier-carrying row sits on a bound with a positive reduced cost, except a fraction `free_frac` that stays strictly
+    inside a wide box with zero reduced cost (dual degeneracy).  `bad_scale_decades` = d scales every row by 10^U(-d, d)."""
+    rng = np.random.default_rng(seed)
+    nnz_row = min(nnz_row, n)
+    xhat = rng.uniform(-1.0, 1.0, size=n)
+    col2 = _distinct_sorted_cols(rng, m, nnz_row, n)
+    val2 = rng.standard_normal((m, nnz_row))
+    active = rng.random(m) < active_frac
+    tight = active | (rng.random(m) < degenerate_frac)
+    mu = np.where(active, rng.uniform(0.5, 1.5, size=m), 0.0)
+    col, val = col2.reshape(-1), val2.reshape(-1)
+    row = np.repeat(np.arange(m), nnz_row)
+    ax = np.bincount(row, weights=val * xhat[col], minlength=m)
+    ub = ax + np.where(tight, 0.0, rng.uniform(0.1, 1.0, size=m))
+    c = -np.bincount(col, weights=mu[row] * val, minlength=n)
+    l_var, u_var = np.full(n, -B), np.full(n, B)
+    in_active = np.zeros(n, dtype=bool)
+    in_active[col2[active].reshape(-1)] = True
+    pin = ~in_active & (rng.random(n) >= free_frac)
+    lower = pin & (rng.random(n) < 0.5)
+    upper = pin & ~lower
+    l_var[lower] = xhat[lower]
+    u_var[upper] = xhat[upper]
+    nu = rng.uniform(0.5, 1.5, size=n)
+    c[lower] += nu[lower]
+    c[upper] -= nu[upper]
+    if bad_scale_decades > 0.0:
+        s = 10.0 ** rng.uniform(-bad_scale_decades, bad_scale_decades, size=m)
+        val = val * s[row]
+        ub = ub * s
+    nz = np.nonzero(c)[0]
+    return SeparableInstance(
+        n=n, l_var=l_var, u_var=u_var, sense="Min", rowptr=(np.arange(m + 1) * nnz_row).astype(np.int64),
+        col=col.astype(np.int32), kind=np.zeros(len(col), dtype=np.uint8), p0=val, p1=np.zeros(len(col)),
+        rconst=np.zeros(m), l_constr=np.full(m, -np.inf), u_constr=ub,
+        obj_col=nz.astype(np.int32), obj_kind=np.zeros(len(nz), dtype=np.uint8), obj_p0=c[nz], obj_p1=np.zeros(len(nz)),
+        obj_const=0.0, xhat=xhat, opt_obj=float(c @ xhat), m_lin=m, m_nl=0,
+        meta=dict(n=n, m_lin=m, seed=seed, lp=True, active_frac=active_frac, degenerate_frac=degenerate_frac,
+                  bad_scale_decades=bad_scale_decades, free_frac=free_frac, lam_sum=0.0, mu_sum=float(mu.sum())))

@@ -55,7 +55,7 @@ struct KtnParams
     purge_age::Int32; purge_margin::Cdouble; purge_min_frac::Cdouble; purge_min_rows::Int64
     lp_dense_after::Int32; cut_cap_factor::Cdouble; cut_cap_min::Int64; lp_stag_factor::Cdouble
     lp_ruiz_warm::Int32; lp_tiled_nnz::Int64; lp_near_check::Int32; dedupe_eps::Cdouble; polish_factor::Cdouble; polish_max_var::Int32; polish_max_iter::Int32
-    epi_shift::Int32; obj_cert_tol::Cdouble
+    epi_shift::Int32; obj_cert_tol::Cdouble; lp_mid_max_var::Int32
 end
 
 struct KtnNlpDesc
@@ -300,7 +300,7 @@ function KatanaHipModel(s)
                     d.lp_gap_floor, d.lp_gap_cap, d.lp_dual_inherit, d.profile, d.purge_age, d.purge_margin,
                     d.purge_min_frac, d.purge_min_rows, d.lp_dense_after, d.cut_cap_factor, d.cut_cap_min,
                     d.lp_stag_factor, d.lp_ruiz_warm, d.lp_tiled_nnz, d.lp_near_check, d.dedupe_eps, d.polish_factor, d.polish_max_var, d.polish_max_iter,
-                    d.epi_shift, d.obj_cert_tol)
+                    d.epi_shift, d.obj_cert_tol, d.lp_mid_max_var)
     h = Ref{Ptr{Void}}(C_NULL)
     code = ccall((:ktn_create, LIB), Cint, (Ref{KtnParams}, Ref{Ptr{Void}}), Ref(prm), h)
     code == 0 || error("ktn_create failed ($code): no MI355X visible? the engine has no CPU path")

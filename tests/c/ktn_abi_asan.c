@@ -25,7 +25,7 @@ int main(void) {
     ktn_default_params(&p);
     ktn_default_params(NULL);
     EXPECT(p.f_tol == 1e-6 && p.cut_coef_rng == 1e9 && p.log_level == 10 && p.iter_cap == 10000 && p.obj_eps == -1.0);   /* src/solver.jl:34-43 */
-    EXPECT(p.epi_shift == 1 && p.polish_max_iter == 30 && p.obj_cert_tol == 1e-6);               /* the last fields: the whole struct was written */
+    EXPECT(p.epi_shift == 1 && p.polish_max_iter == 30 && p.obj_cert_tol == 1e-6 && p.lp_mid_max_var == 512);               /* the last fields: the whole struct was written */
     EXPECT(ktn_abi_version() == KTN_ABI_VERSION);
     EXPECT(ktn_sizeof_params() == (int64_t)sizeof(ktn_params) && ktn_sizeof_nlp_desc() == (int64_t)sizeof(ktn_nlp_desc));
 

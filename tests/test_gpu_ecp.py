@@ -240,20 +240,13 @@ def test_full_batch_of_512_cfg5_instances_one_workgroup_per_instance():
     insts = [ktn.instances.make_config("cfg5_one", seed=s) for s in range(512)]
     res, wall = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts, fused=True, per_instance_lp=True)
     assert len(res) == 512 and res[0]["blk_lp_launches"] >= 2 and res[0]["blk_lp_fallbacks"] == 0
-    beyond_reference_tol = 0
     for r, inst in zip(res, insts):
         assert r["status"] == "Optimal"
-        # This is the intermediate form (off by default): every instance ends within the a-priori bound of
-        # the stop rule, and all but a handful within the reference's own 1e-6 / 1e-6 (test/runtests.jl:16-17) -- an instance
-        # whose objective happens to be small in magnitude (|c'x| < 1 from 1e3 terms of order one) has nothing but f_tol times
-        # its multipliers to go by.  The two default forms (device-side loop, fused global loop) are asserted at the
-        # reference tolerance for every instance in the tests below.
-        err = abs(r["objval"] - inst.opt_obj)
-        assert err <= planted_obj_bound(inst) and err <= 3e-6 * max(1.0, abs(inst.opt_obj))
-        beyond_reference_tol += err > 1e-6 * max(1.0, abs(inst.opt_obj))
+        # the intermediate form too owes the reference's 1e-6 / 1e-6 (test/runtests.jl:16-17) to EVERY instance: the engine
+        # evaluates the objective certificate per block (k_cert_blocks) and keeps refining while any instance exceeds its own target
+        assert_planted_objective(r["objval"], inst)
         assert max_nl_violation(inst, r["x"]) <= 1e-6 * (1 + 1e-6)
         assert np.max(np.abs(r["x"] - inst.xhat)) <= 1e-3
-    assert beyond_reference_tol <= 3, beyond_reference_tol
     # the same batch through the global first-order loop: the same answers up to the stop rule
     ref, _ = ktn.solve_batch(ktn.KatanaSolver(log_level=0), insts[:64], fused=True, per_instance_lp=False, device_loop=False)
     for a, b, inst in zip(res[:64], ref, insts[:64]):
@@ -376,8 +369,14 @@ def test_resolve_of_an_unchanged_lp_reuses_the_setup():
     copies and the sigma_max estimate are taken over (lp_setup_reuses), the answer is the planted optimum"""
     inst = ktn.instances.make_config("cfg3", seed=0)
     m = hip_load_instance(ktn, inst)
+    # (whether a solve of the cutting-plane loop meets this situation depends on its trajectory -- cfg3 seed 0 did until the
+    #  round-4 primal-weight rule -- so the two solves are asked for directly: loose, then tight, on the matrix as loaded)
+    st1, it1 = m.lp_solve(row_tol=1e-2, gap_tol=1e-2)
+    obj1 = m.getobjval()
+    st2, it2 = m.lp_solve(row_tol=1e-7, gap_tol=1e-7)
+    assert st1 == st2 == "Optimal" and m.stat("lp_setup_reuses") >= 1
+    assert abs(m.getobjval() - obj1) <= 2e-2 * (1.0 + abs(obj1))       # the same LP, solved tighter from the loose solve's point
     assert m.optimize() == "Optimal"
-    assert m.stat("lp_setup_reuses") >= 1
     assert_planted_objective(m.getobjval(), inst)
 
 

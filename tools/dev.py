@@ -9,7 +9,10 @@
     python tools/dev.py kernel_us [n ...]                              mean launch duration of the LP step kernels against LP size
     python tools/dev.py reload                                         512 x cfg5 batches reloaded on one handle vs fresh handles
 
-A <shape> is family:objective:n:m_nl:k, e.g. explog:quad:100000:10000:32 (instances.make_instance); a <config> is a key of
+    python tools/dev.py offfamily <wall_s> <s0> <s1> <shape> ... [opt=val ...]  off-family battery: each solve stepwise under a wall budget
+
+A <shape> is family:objective:n:m_nl:k[:bound_frac[:pivot_boost]], e.g. explog:quad:100000:10000:32 or explog:linear:1000:100:32:0.5:0
+(instances.make_instance; `cfg3:::::0.5` = a BASELINE config with another bound_frac); a <config> is a key of
 instances.CONFIGS.  opt=val are KatanaSolver keywords (ktn_params fields).
 """
 import os
@@ -31,8 +34,17 @@ def _opts(args):
 
 def _make(ktn, spec, seed):
     if ":" in spec:
-        fam, obj, n, m_nl, k = spec.split(":")
-        return ktn.instances.make_instance(n=int(n), m_nl=int(m_nl), k=int(k), family=fam, seed=seed, objective=obj)
+        f = spec.split(":")
+        fam, obj, n, m_nl, k = f[:5]
+        if fam in ktn.instances.CONFIGS:                 # cfg3::::: 0.5 -> a BASELINE config with another bound_frac
+            kw = dict(ktn.instances.CONFIGS[fam])
+        else:
+            kw = dict(n=int(n), m_nl=int(m_nl), k=int(k), family=fam, objective=obj)
+        if len(f) > 5 and f[5] != "":
+            kw["bound_frac"] = float(f[5])
+        if len(f) > 6 and f[6] != "":
+            kw["pivot_boost"] = bool(int(f[6]))
+        return ktn.instances.make_instance(seed=seed, **kw)
     return ktn.instances.make_config(spec, seed=seed)
 
 
@@ -73,7 +85,7 @@ def cmd_steps(ktn, args):
     while not done and m.numiters() < max_steps:
         t = time.time(); done = m.ecp_step(); dt = time.time() - t
         cur = {k: m.stat(k) for k in STEP_KEYS}
-        print("step %3d %.3fs rows %d cuts %d obj %.9g " % (m.numiters(), dt, m.lp_num_rows(), m.numcuts(), m.getobjval()) +
+        print("step %3d %.3fs rows %d cuts %d obj %.9g nviol %d maxviol %.3e " % (m.numiters(), dt, m.lp_num_rows(), m.numcuts(), m.getobjval(), m.stat("last_nviol"), m.stat("last_maxviol")) +
               " ".join("%s=%g" % (k.replace("lp_", ""), cur[k] - prev[k]) for k in STEP_KEYS), flush=True)
         prev = cur
     print(m.optimize_end(), "wall %.3fs" % (time.time() - t0), "obj", m.getobjval(), "planted", inst.opt_obj, "relerr %.2e" % _relerr(m, inst))
@@ -95,6 +107,33 @@ def cmd_seeds(ktn, args):
         print("  seed %d: %s %.3fs iters %d relerr %.1e" % (seed, st, w, m.numiters(), errs[-1]), flush=True)
     print("%s seeds %d-%d %s: mean %.3fs median %.3fs max %.3fs total pdhg %d refined %d ecp iters %s max relerr %.1e | %s" % (
         name, n0, n1 - 1, kw, np.mean(ws), np.median(ws), np.max(ws), tot_p, refine, its, max(errs), " ".join("%.3f" % w for w in ws)))
+
+
+def cmd_offfamily(ktn, args):
+    """Solves off the non-degenerate-vertex family (the degeneracy dial of instances.make_instance), each stepwise so that a
+    solve that crawls is cut off at the wall budget and reported instead of eating the GPU budget."""
+    import numpy as np
+    wall, n0, n1 = float(args[0]), int(args[1]), int(args[2])
+    shapes = [a for a in args[3:] if ":" in a]
+    kw = _opts([a for a in args[3:] if ":" not in a])
+    for spec in shapes:
+        for seed in range(n0, n1):
+            inst = _make(ktn, spec, seed)
+            m = _load(ktn, inst, log_level=0, **kw)
+            t0 = time.time()
+            m.optimize_begin()
+            done = False
+            while not done and time.time() - t0 < wall:
+                done = m.ecp_step()
+            st = m.optimize_end() if done else "WALL"
+            w = time.time() - t0
+            x = m.getsolution()[:inst.n]
+            err = m.getobjval() - inst.opt_obj
+            tol = max(1e-6, 1e-6 * max(abs(m.getobjval()), abs(inst.opt_obj)))
+            print("%-40s seed %d: %-9s wall %7.2fs ecp %5d polish %3d pdhg %9d rows %7d obj %.9g planted %.9g err %+.2e (%s) dense %d mid %d piv %d cold %d fb %d lp_s %.2f" % (
+                spec, seed, st, w, m.numiters(), m.stat("polish_iters"), m.stat("pdhg_iters"), m.lp_num_rows(), m.getobjval(), inst.opt_obj,
+                err, "ok" if abs(err) <= tol else "MISS", m.stat("dense_lp_solves"), m.stat("mid_lp_solves"), m.stat("mid_lp_pivots"),
+                m.stat("mid_lp_cold_starts"), m.stat("mid_lp_fallbacks"), m.stat("lp_time_s")), flush=True)
 
 
 def cmd_knobs(ktn, args):

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round profile: rocprofv3 kernel stats of the bench command, PMC FETCH_SIZE / WRITE_SIZE passes (separate passes: gpurun
 # refuses --pmc together with trace domains other than --kernel-trace), the same for the HBM-regime SpMV microbenchmark and
-# the HBM-resident sweep.  Writes summaries under gpurun_out/prof_r03/ (copy what is to be judged into profiles/).
+# the HBM-resident sweep.  Writes summaries under gpurun_out/prof_r04/ (copy what is to be judged into profiles/).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof_r03
+OUT=$R/gpurun_out/prof_r04
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run_stats() {  # name, args...
