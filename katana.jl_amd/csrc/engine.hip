@@ -301,7 +301,8 @@ struct Engine {
     DBuf<int32_t> ds_W, ds_valid;
     DBuf<double> ds_dense, ds_out;
     // exact mid-size LP (mid_lp.hpp): basis inverse, working set, x and multipliers persist across the ECP iterations
-    DBuf<double> md_Binv, md_hW, md_x, md_lam, md_u, md_d, md_r, md_pv, md_c;
+    DBuf<double> md_Binv, md_hW, md_x, md_lam, md_u, md_d, md_r, md_pv, md_c, md_aug, md_prow, md_fcol;
+    int64_t md_since_refactor = 0;
     int64_t mid_backoff = 0, mid_backoff_len = 0;      // after a failed exact solve the first-order method carries on alone for a while
     DBuf<int32_t> md_W, md_pi, md_lost;
     DBuf<MidState> md_st;
@@ -2267,16 +2268,34 @@ bool Engine::lp_solve_mid(LpResult* R) {
         hipLaunchKernelGGL(k_mid_resid_norm, dim3(1), dim3(256), 0, stream, P, 1);
         hipLaunchKernelGGL(k_mid_lambda, dim3(g_n), dim3(256), 0, stream, P);
     };
+    // B^-1 afresh from the working set (mid_lp.hpp "refactorisation"), then x and lambda from their definitions
+    auto refactor = [&]() {
+        md_aug.resize((size_t)n * 2 * n, stream); md_prow.resize((size_t)2 * n, stream); md_fcol.resize((size_t)n, stream);
+        hipLaunchKernelGGL(k_mid_gj_build, dim3((unsigned)n), dim3(256), 0, stream, P, md_aug.p);
+        const unsigned g_2n = (unsigned)ceil_div(2 * n, 256), g_aug = (unsigned)ceil_div((int64_t)n * 2 * n, 256);
+        for (int col = 0; col < n; ++col) {
+            hipLaunchKernelGGL(k_mid_gj_pivot, dim3(1), dim3(256), 0, stream, P, (const double*)md_aug.p, col);
+            hipLaunchKernelGGL(k_mid_gj_swap, dim3(g_2n), dim3(256), 0, stream, P, md_aug.p, col, md_prow.p);
+            hipLaunchKernelGGL(k_mid_gj_col, dim3(g_n), dim3(256), 0, stream, P, (const double*)md_aug.p, col, md_fcol.p);
+            hipLaunchKernelGGL(k_mid_gj_elim, dim3(g_aug), dim3(256), 0, stream, P, md_aug.p, col, (const double*)md_prow.p, (const double*)md_fcol.p);
+        }
+        hipLaunchKernelGGL(k_mid_gj_store, dim3(g_nn), dim3(256), 0, stream, P, (const double*)md_aug.p);
+        refine();
+        md_since_refactor = 0;
+        stats["mid_lp_refactors"] += 1.0;
+    };
     MidState hs;
     int total_pivots = 0, status = 4;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (!md_valid) {
             hipLaunchKernelGGL(k_mid_init, dim3(g_nn), dim3(256), 0, stream, P);
             stats["mid_lp_cold_starts"] += 1.0;
+            md_since_refactor = 0;
         } else {
             hipLaunchKernelGGL(k_mid_rearm, dim3(1), dim3(1), 0, stream, md_st.p);
+            if (md_since_refactor >= kMidRefactor) refactor();
         }
-        int refined_at = -1, refinements = 0;
+        int refined_at = -1, refinements = 0, pivots_seen = 0;
         bool bad_inverse = false;
         status = 4;
         for (;;) {
@@ -2290,7 +2309,13 @@ bool Engine::lp_solve_mid(LpResult* R) {
             check_launch();
             KTN_HIP(hipMemcpyAsync(&hs, md_st.p, sizeof(hs), hipMemcpyDeviceToHost, stream));
             sync();
-            if (hs.status == 0) continue;
+            md_since_refactor += hs.pivots - pivots_seen;
+            pivots_seen = hs.pivots;
+            if (hs.gj_singular) { bad_inverse = true; break; }            // the working set itself is (numerically) dependent: cold start
+            if (hs.status == 0) {
+                if (md_since_refactor >= kMidRefactor) refactor();
+                continue;
+            }
             if (hs.status == 1) {
                 if (refined_at == hs.pivots) {          // the confirming price after the refinement found nothing either
                     if (!(hs.resid <= 1e-7 * hs.scale)) { bad_inverse = true; break; }

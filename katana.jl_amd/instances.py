@@ -373,3 +373,19 @@ def make_lp(n, m, seed=0, nnz_row=8, B=10.0, active_frac=0.3, degenerate_frac=0.
         obj_const=0.0, xhat=xhat, opt_obj=float(c @ xhat), m_lin=m, m_nl=0,
         meta=dict(n=n, m_lin=m, seed=seed, lp=True, active_frac=active_frac, degenerate_frac=degenerate_frac,
                   bad_scale_decades=bad_scale_decades, free_frac=free_frac, lam_sum=0.0, mu_sum=float(mu.sum())))
+
+
+def lp_battery_case(i):
+    """Case i of the LP-only battery (tools/lp_battery.py, tests/test_gpu_lp.py): sizes 1e3 ... 1e4 columns, 0.5 ... 2 rows per
+    column, and five kinds in turn -- plain, primal-degenerate vertex, rows scaled over six decades, degenerate + scaled +
+    dual-degenerate (free columns with zero reduced cost), heavily degenerate.  Returns the keyword arguments of make_lp."""
+    rng = np.random.default_rng(1000 + i)
+    n = int(10 ** rng.uniform(3.0, 4.0))
+    m = int(n * rng.uniform(0.5, 2.0))
+    kw = dict(n=n, m=m, seed=i, nnz_row=int(rng.integers(4, 17)))
+    kind = i % 5
+    if kind == 1: kw.update(degenerate_frac=0.3)
+    if kind == 2: kw.update(bad_scale_decades=3.0)
+    if kind == 3: kw.update(degenerate_frac=0.2, bad_scale_decades=2.0, free_frac=0.2)
+    if kind == 4: kw.update(active_frac=0.6, degenerate_frac=0.4)
+    return kw

@@ -336,3 +336,48 @@ def test_append_only_mirror_update_gives_the_sorted_mirror_bit_for_bit(monkeypat
         assert a[4] >= a[2] - 3 and b[4] == 0 and b[5] >= b[2] - 3       # merges in the default build, sorts only when asked
         if not solver:
             assert a[5] <= 2                                              # (a sort only for the first mirror; the pool is never purged at this size)
+
+
+@pytest.mark.parametrize("first", [0, 10, 20, 30, 40])
+def test_lp_battery_against_highs_and_the_planted_optimum(first):
+    """50 random sparse LPs, 1e3 ... 1e4 columns, degenerate vertices, rows scaled over six decades and
+    dual-degenerate free columns included (instances.lp_battery_case), through ktn_lp_solve.  Every case: `:Optimal`, objective
+    within 1e-7 relative of the planted primal-dual optimum, rows and bounds feasible.  The 15 cases below 1 700 columns also
+    against HiGHS's committed status and objective (tests/golden/lp_battery_highs.json; on the larger ones HiGHS -- simplex
+    and interior point -- does not finish within minutes here, while the engine needs 300 - 2 700 iterations, 3 - 20 ms)."""
+    import json, os
+    fx = {c["case"]: c for c in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lp_battery_highs.json")))["cases"]}
+    for i in range(first, first + 10):
+        inst = ktn.instances.make_lp(**ktn.instances.lp_battery_case(i))
+        m = hip_load_instance(ktn, inst)
+        st, iters = m.lp_solve(row_tol=1e-8, gap_tol=1e-8)
+        assert st == "Optimal" and iters > 0 and m.stat("mid_lp_solves") == 0, (i, st)
+        scale = max(1.0, abs(inst.opt_obj))
+        assert abs(m.getobjval() - inst.opt_obj) <= 1e-7 * scale, (i, m.getobjval(), inst.opt_obj)
+        if i in fx:
+            assert fx[i]["status"] == st and abs(m.getobjval() - fx[i]["objective"]) <= 1e-7 * scale, (i, m.getobjval(), fx[i])
+        x = m.getsolution()
+        rows = np.repeat(np.arange(inst.num_constr), np.diff(inst.rowptr))
+        ax = np.bincount(rows, weights=inst.p0 * x[inst.col], minlength=inst.num_constr)
+        assert np.max(ax - inst.u_constr) <= 1e-7                                            # (the solve's row tolerance was 1e-8, absolute)
+        assert np.all(x >= inst.l_var - 1e-12) and np.all(x <= inst.u_var + 1e-12)
+
+
+def test_exact_mid_size_lp_solver_matches_highs_when_forced():
+    """csrc/mid_lp.hpp on its own: lp_dense_after < 0 sends an LP of 33 .. lp_mid_max_var columns straight to the dual
+    active-set solver (basis inverse in device memory, cost perturbation against dual degeneracy).  Objective against HiGHS."""
+    from oracle.lp import LinearModel
+    for kw in (dict(n=120, m=150, seed=3), dict(n=300, m=260, seed=4, degenerate_frac=0.3), dict(n=200, m=400, seed=5, free_frac=0.3)):
+        inst = ktn.instances.make_lp(**kw)
+        m = hip_load_instance(ktn, inst, lp_dense_after=-1)
+        st, pivots = m.lp_solve()
+        assert st == "Optimal" and m.stat("mid_lp_solves") == 1 and m.stat("mid_lp_fallbacks") == 0 and pivots > 0
+        lm = LinearModel()
+        lm.add_variables(inst.l_var, inst.u_var)
+        c = np.zeros(inst.n); c[inst.obj_col] = inst.obj_p0
+        lm.set_objective("Min", np.arange(inst.n), c, 0.0)
+        lm.add_rows(inst.rowptr, inst.col, inst.p0, inst.l_constr, inst.u_constr, assume_unique=True)
+        assert lm.solve() == "Optimal"
+        assert abs(m.getobjval() - lm.getobjval()) <= 1e-7 * max(1.0, abs(lm.getobjval()))
+        x = m.getsolution()
+        assert np.all(x >= inst.l_var - 1e-9) and np.all(x <= inst.u_var + 1e-9)

@@ -11,17 +11,7 @@ import numpy as np
 import katana_jl_amd as ktn
 
 
-def battery_case(i):
-    rng = np.random.default_rng(1000 + i)
-    n = int(10 ** rng.uniform(3.0, 4.0))
-    m = int(n * rng.uniform(0.5, 2.0))
-    kind = i % 5
-    kw = dict(n=n, m=m, seed=i, nnz_row=int(rng.integers(4, 17)))
-    if kind == 1: kw.update(degenerate_frac=0.3)
-    if kind == 2: kw.update(bad_scale_decades=3.0)
-    if kind == 3: kw.update(degenerate_frac=0.2, bad_scale_decades=2.0, free_frac=0.2)
-    if kind == 4: kw.update(active_frac=0.6, degenerate_frac=0.4)
-    return kw
+battery_case = ktn.instances.lp_battery_case
 
 
 def main():
