@@ -157,8 +157,56 @@ struct LpResult {
     bool stag_exit = false;         // ended through the primal-stagnation exit (objective flat, gap within lp_stag_factor x tolerance)
 };
 
+// Development switches (tools/README.md), parsed ONCE PER HANDLE at ktn_create from the KTN_* environment of that moment: two
+// handles made under different settings can be A/B'd in one process, nothing is `static`, and -- unlike the getenv calls that
+// sat inside lp_solve_core until round 3 -- every one of them is listed here, next to ktn_params, with what ships.
+struct DevParams {
+    bool no_pinned_check = false, debug_load = false, no_csc_merge = false, tiled_general_build = false, debug_blocks = false,
+         no_tiled_check = false, no_setup_reuse = false, debug_lp = false, no_packed = false, force_collective = false;
+    int sweep_rows = 0;            // KTN_SWEEP_ROWS       NL rows per lane group of the sweep (0 = by size)
+    int blk_cfg = -1;              // KTN_BLK_CFG          tuning variant of the column-blocked sweep
+    int sweep_blocked = -1;        // KTN_SWEEP_BLOCKED    0 = row kernel instead of the column-blocked sweep
+    int tiled_wg = 2;              // KTN_TILED_WG         workgroups per CU of k_spmv_tiled
+    int ecp_power = 20;            // KTN_ECP_POWER        power passes of the device-side batch loop
+    int grp_rows = 0, grp_cols = 0;// KTN_GRP_ROWS / COLS  lanes per LP row / column (0 = by average length)
+    int tiled = -1;                // KTN_TILED            force the tiled SpMV off (0) / on (1)
+    double smax_reuse = 0.0;       // KTN_SMAX_REUSE       reuse of the sigma_max estimate (measured: harmful)
+    int power_passes = 0;          // KTN_POWER_PASSES     power-iteration passes (0 = 8)
+    int omega_robust = 1;          // KTN_OMEGA_ROBUST     0 = initial primal weight from the plain 2-norm ratio
+    int packed_trips = 0;          // KTN_PACKED_TRIPS     outputs per lane group of the packed steps (0 = default)
+    int first_chunk = 31;          // KTN_FIRST_CHUNK      iterations before the first check after a restart
+    int stag_chunk = 0;            // KTN_STAG_CHUNK       check cadence while only the objective is unsettled (measured, off)
+    int near_chunk = -1;           // KTN_NEAR_CHUNK       overrides lp_near_check
+    int stag_checks = 2;           // KTN_STAG_CHECKS      flat checks the stagnation exit asks for
+    double flat_factor = 0.4;      // KTN_FLAT_FACTOR      "flat" = within this fraction of the gap tolerance
+    int omega_art = 1;             // KTN_OMEGA_ART        0 = no primal-weight update on restarts the residual did not earn
+    double omega_art_k = 256.0;    // KTN_OMEGA_ART_K      period length at which such a restart's ratio gets the full weight 0.5
+    double omega_art_clamp = 0.0, omega_clamp = 0.0, omega_clamp_down = 0.0;   // KTN_OMEGA_ART_CLAMP / _CLAMP / _CLAMP_DOWN (measured, off)
+    double ipc_timeout_s = 20.0;   // KTN_IPC_TIMEOUT_S    spin bound of the peer-buffer transport
+    static bool flag(const char* k) { return std::getenv(k) != nullptr; }
+    static int geti(const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; }
+    static double getd(const char* k, double d) { const char* v = std::getenv(k); return v ? std::atof(v) : d; }
+    void from_env() {
+        no_pinned_check = flag("KTN_NO_PINNED_CHECK"); debug_load = flag("KTN_DEBUG_LOAD"); no_csc_merge = flag("KTN_NO_CSC_MERGE");
+        tiled_general_build = flag("KTN_TILED_GENERAL_BUILD"); debug_blocks = flag("KTN_DEBUG_BLOCKS"); no_tiled_check = flag("KTN_NO_TILED_CHECK");
+        no_setup_reuse = flag("KTN_NO_SETUP_REUSE"); debug_lp = flag("KTN_DEBUG_LP"); no_packed = flag("KTN_NO_PACKED");
+        force_collective = flag("KTN_FORCE_COLLECTIVE");
+        sweep_rows = geti("KTN_SWEEP_ROWS", sweep_rows); blk_cfg = geti("KTN_BLK_CFG", blk_cfg); sweep_blocked = geti("KTN_SWEEP_BLOCKED", sweep_blocked);
+        tiled_wg = geti("KTN_TILED_WG", tiled_wg); ecp_power = geti("KTN_ECP_POWER", ecp_power);
+        grp_rows = geti("KTN_GRP_ROWS", grp_rows); grp_cols = geti("KTN_GRP_COLS", grp_cols); tiled = geti("KTN_TILED", tiled);
+        smax_reuse = getd("KTN_SMAX_REUSE", smax_reuse); power_passes = geti("KTN_POWER_PASSES", power_passes);
+        omega_robust = geti("KTN_OMEGA_ROBUST", omega_robust); packed_trips = geti("KTN_PACKED_TRIPS", packed_trips);
+        first_chunk = geti("KTN_FIRST_CHUNK", first_chunk); stag_chunk = geti("KTN_STAG_CHUNK", stag_chunk); near_chunk = geti("KTN_NEAR_CHUNK", near_chunk);
+        stag_checks = geti("KTN_STAG_CHECKS", stag_checks); flat_factor = getd("KTN_FLAT_FACTOR", flat_factor);
+        omega_art = geti("KTN_OMEGA_ART", omega_art); omega_art_k = getd("KTN_OMEGA_ART_K", omega_art_k);
+        omega_art_clamp = getd("KTN_OMEGA_ART_CLAMP", omega_art_clamp); omega_clamp = getd("KTN_OMEGA_CLAMP", omega_clamp);
+        omega_clamp_down = getd("KTN_OMEGA_CLAMP_DOWN", omega_clamp_down); ipc_timeout_s = getd("KTN_IPC_TIMEOUT_S", ipc_timeout_s);
+    }
+};
+
 struct Engine {
     ktn_params prm;
+    DevParams dev;
     std::string err;
     hipStream_t stream = nullptr;
     int device = 0;
@@ -409,6 +457,7 @@ struct Engine {
     size_t ev_used = 0;
 
     explicit Engine(const ktn_params& p) : prm(p) {
+        dev.from_env();
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
             throw Error(KTN_E_NODEVICE, "no HIP device visible: the Katana HIP engine has no CPU path");
@@ -425,7 +474,7 @@ struct Engine {
         KTN_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         partials.resize((size_t)kRedBlocks * kChkQ * 2, stream);
         chkout.resize(kChkQ * 2 + 16, stream);
-        if (std::getenv("KTN_NO_PINNED_CHECK") == nullptr &&
+        if (!dev.no_pinned_check &&
             hipHostMalloc((void**)&h_chk, sizeof(double) * (2 * kChkQ + 16), hipHostMallocMapped) == hipSuccess) {
             if (hipHostGetDevicePointer((void**)&h_chk_dev, h_chk, 0) != hipSuccess) { (void)hipHostFree(h_chk); h_chk = nullptr; h_chk_dev = nullptr; }
         } else {
@@ -676,7 +725,7 @@ struct Engine {
         } else {
             // many short rows: several rows per lane group (k_sep_sweep) once one row per group would make more wavefronts
             // than the chip holds several times over; small sweeps keep one row per group and all the parallelism
-            static const int rows_env = std::getenv("KTN_SWEEP_ROWS") ? std::atoi(std::getenv("KTN_SWEEP_ROWS")) : 0;
+            const int rows_env = dev.sweep_rows;
             const int64_t waves1 = m_nl * grp_sweep / 64, resident = (int64_t)num_cus * 32;
             const int R = rows_env > 0 ? rows_env : (waves1 >= 16 * resident ? 4 : waves1 >= 8 * resident ? 2 : 1);
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -912,7 +961,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     KTN_REQUIRE(num_var >= 0 && num_constr >= 0, "negative sizes");
     KTN_REQUIRE(d->num_var == num_var && d->num_constr == num_constr, "nlp description sizes disagree with loadproblem");
     KTN_REQUIRE(num_var + 1 < ((int64_t)1 << kKindShift), "num_var too large for the packed 29-bit column index");
-    static const bool dbg_load = std::getenv("KTN_DEBUG_LOAD") != nullptr;
+    const bool dbg_load = dev.debug_load;
     auto tl0 = std::chrono::steady_clock::now();
     auto lapl = [&](const char* what) {
         if (!dbg_load) return;
@@ -1123,12 +1172,12 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
     {
         // Measured on cfg3_hbm (2e7 entries, 2048 per row): exp/log atoms 156 -> 123 us, quadratic atoms 171 -> 114 us.
         // KTN_SWEEP_BLOCKED=0 switches it off (tests compare the two paths).
-        if (const char* c = std::getenv("KTN_BLK_CFG")) blk_cfg = std::atoi(c);
+        if (dev.blk_cfg >= 0) blk_cfg = dev.blk_cfg;
         blk_cols = (blk_cfg == 2) ? 16384 : 8192;
         blk_wg_per_cu = (blk_cfg == 2) ? 1 : 2;
-        const char* env = std::getenv("KTN_SWEEP_BLOCKED");
+        const bool env = dev.sweep_blocked >= 0;
         blk_on = m_nl > 0 && n_lp >= 2 * blk_cols && (double)nnz_nl / (double)m_nl >= 256.0;
-        if (env) blk_on = blk_on && std::atoi(env) != 0;
+        if (env) blk_on = blk_on && dev.sweep_blocked != 0;
         blk_nb = ceil_div(n_lp, blk_cols);
         if (blk_on && (double)(m_nl + 1) * blk_nb > 4e8) blk_on = false;
         for (size_t si = 0; blk_on && si < h_nlrows.size(); ++si) {
@@ -1384,7 +1433,7 @@ void Engine::reset() {
 // LP: column mirror, scaling, PDHG
 // ------------------------------------------------------------------------------------
 void Engine::rebuild_csc() {
-    const bool no_merge = std::getenv("KTN_NO_CSC_MERGE") != nullptr;       // (tests: the sort path for every solve)
+    const bool no_merge = dev.no_csc_merge;       // (tests: the sort path for every solve)
     c_val.resize((size_t)NNZ + 1, stream);
     // (long columns: the merge orders a column's new entries by insertion -- fine for the 0.3 entries a column gains per sweep,
     //  quadratic for a column that gains one per cut; the radix sort does not care)
@@ -1696,7 +1745,7 @@ bool Engine::build_tiled(TiledBuf& T, int64_t n_out, int64_t n_in, const int64_t
     T.idx.resize((size_t)NNZ + 1, stream);
     T.val.resize((size_t)NNZ + 1, stream);
     int32_t ovf = 0;
-    const bool no_sorted = std::getenv("KTN_TILED_GENERAL_BUILD") != nullptr;             // (tests: the general kernels)
+    const bool no_sorted = dev.tiled_general_build;             // (tests: the general kernels)
     // first the run-based kernels (entries of an output in ascending input order: what the LP's rows and the mirror's columns
     // are); an output that is not ascending makes them give up (bit 1) and the general kernels build the copy
     for (int pass = no_sorted ? 1 : 0; pass < 2; ++pass) {
@@ -1723,7 +1772,7 @@ bool Engine::build_tiled(TiledBuf& T, int64_t n_out, int64_t n_in, const int64_t
     }
     // two 1024-thread workgroups per CU (80 KB of LDS each): a persistent grid over the (tile, block) units
     const int64_t U = T.tiles * T.nb_in;
-    static const int wg_per_cu = std::getenv("KTN_TILED_WG") ? std::atoi(std::getenv("KTN_TILED_WG")) : 2;
+    const int wg_per_cu = dev.tiled_wg;
     T.grid = std::max<int64_t>(std::min<int64_t>((int64_t)wg_per_cu * num_cus, U), 1);
     {
         std::vector<int32_t> pc((size_t)T.tiles);
@@ -1892,7 +1941,7 @@ bool Engine::optimize_blocks_device(int cap_mul) {
     //  slowest instance against 64 -- 512 x cfg5: max 15 842 -> 5 008, the launch 0.131 -> 0.097 s)
     B.check_every = std::min(B.check_every, 24);
     B.near_chunk = prm.lp_near_check; B.ruiz_iters = prm.lp_ruiz_iters; B.nmax = blk_nmax; B.mmax = mmax;
-    B.power_passes = std::getenv("KTN_ECP_POWER") ? std::atoi(std::getenv("KTN_ECP_POWER")) : 20;
+    B.power_passes = dev.ecp_power;
     if (lds > lds_set_ecp) {
         KTN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ecp_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set_ecp = lds;
@@ -1908,7 +1957,7 @@ bool Engine::optimize_blocks_device(int cap_mul) {
         if ((int)o[0] != KTN_STATUS_OPTIMAL) ok = false;
         obj += o[2]; it_max = std::max(it_max, o[1]); cuts += o[3]; pd += o[4]; rows += o[6];
     }
-    if (std::getenv("KTN_DEBUG_BLOCKS")) {
+    if (dev.debug_blocks) {
         std::vector<std::pair<double, int>> v;
         for (int bb = 0; bb < nb; ++bb) v.push_back({res[(size_t)bb * 8 + 4], bb});
         std::sort(v.begin(), v.end());
@@ -2057,7 +2106,7 @@ void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double si
     chk_part.resize((size_t)(brow + n_long + bcol) * kChkQ, stream);
     double* prow = chk_part.p;
     double* pcol = chk_part.p + (size_t)(brow + n_long) * kChkQ;
-    static const bool tiled_chk_off = std::getenv("KTN_NO_TILED_CHECK") != nullptr;
+    const bool tiled_chk_off = dev.no_tiled_check;
     if (tiled_on && m > 0 && !tiled_chk_off) {
         // the four SpMV passes of a check through the tiled copy (kernels.hpp "check iteration on the tiled copy"); row-sharded:
         // the two column-side vectors are this rank's partials and are summed over the ranks -- the same sequence of
@@ -2382,7 +2431,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     ensure_matrix(want_shift(mode));
     lap("lp_csc_time_s", tp);
     // (row-sharded: the versions are per rank while the scaling is a collective -- no reuse there)
-    static const bool no_reuse = std::getenv("KTN_NO_SETUP_REUSE") != nullptr;
+    const bool no_reuse = dev.no_setup_reuse;
     const bool same_matrix = !no_reuse && !row_sharded() && scaled_version == lp_version && scaled_identity == identity_scaling;
     find_long_rows();                                   // (before the scaling: its row passes treat long rows separately)
     if (!same_matrix) compute_scaling(identity_scaling);
@@ -2406,14 +2455,14 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     const double avg_r = m ? (double)NNZ / (double)m : 1.0, avg_c = n ? (double)NNZ / (double)n : 1.0;
     grp_rows = pick_group(avg_r);
     grp_cols = pick_group(avg_c);
-    if (const char* g = std::getenv("KTN_GRP_ROWS")) grp_rows = std::atoi(g);
-    if (const char* g = std::getenv("KTN_GRP_COLS")) grp_cols = std::atoi(g);
+    if (dev.grp_rows > 0) grp_rows = dev.grp_rows;
+    if (dev.grp_cols > 0) grp_cols = dev.grp_cols;
     SpMat A{lp_rowptr.p, lp_col.p, r_sval.p};
     SpMat AT{c_ptr.p, c_row.p, c_sval.p};
     // LPs beyond the caches: tiled copies of A^ and A^' (kernels.hpp "tiled SpMV") serve the plain steps and the check
     // iterations; the power iteration keeps the CSR / CSC kernels
     {
-        static const char* tenv = std::getenv("KTN_TILED");
+        const bool tenv = dev.tiled >= 0;
         // ... and dense enough: every (tile, block) unit stages a 64 KB block of the input vector, so a matrix with few entries
         // per unit pays more for the staging than for its entries (n = 1e6, 5.8e6 entries: 350 per unit, 1.31 s tiled against
         // 0.49 s with the CSR kernels; cfg4: 9 500 per unit)
@@ -2421,7 +2470,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         const int64_t units_tt = ceil_div(n_lp, (int64_t)kTileOut) * ceil_div(M, (int64_t)kTileIn);
         tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn &&
                    NNZ >= 4096 * std::max(units_t, units_tt);
-        if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0;
+        if (tenv) tiled_on = dev.tiled != 0 && M > 0 && NNZ > 0;
         if (same_matrix) tiled_on = tiled_built;            // the copies of the previous solve (or their absence) still fit
         else if (tiled_on) {
             auto tt = std::chrono::steady_clock::now();
@@ -2447,7 +2496,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     bool have_power = false;
     // sigma_max of the previous solve is reused while the matrix has grown by less than KTN_SMAX_REUSE (a fraction of its
     // rows) since the estimate was made (development switch, default off)
-    static const double smax_reuse = std::getenv("KTN_SMAX_REUSE") ? std::atof(std::getenv("KTN_SMAX_REUSE")) : 0.0;
+    const double smax_reuse = dev.smax_reuse;
     const bool reuse_smax = mode == 0 && smax_reuse > 0.0 && smax_rows > 0 && m >= smax_rows && !row_sharded() &&
                             (double)(m - smax_rows) <= smax_reuse * (double)smax_rows && smax_prev > 0.0;
     if (same_matrix && smax_version == lp_version && smax_prev > 0.0) smax = smax_prev;       // same matrix, same estimate
@@ -2468,7 +2517,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         };
         dot_dev(power_v.p, nrm);
         LAUNCH_1(k_normalize, n, stream, n, power_v.p, nrm, pv.p);
-        static const int passes_env = std::getenv("KTN_POWER_PASSES") ? std::atoi(std::getenv("KTN_POWER_PASSES")) : 0;
+        const int passes_env = dev.power_passes;
         const int iters = passes_env > 0 ? passes_env : 8;
         // The iterate is re-normalised only every fourth pass (and before the last, whose ||A'A v|| with ||v|| = 1 is the
         // estimate): with ||A^||_2 <= 1 after the Pock-Chambolle pass the un-normalised vector only shrinks slowly, and the
@@ -2514,7 +2563,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     // factors of 1e5-1e6 and with them c^_j ~ 1e6: three such columns among 1e5 make ||c^||_2 a thousand times the typical
     // magnitude -- cfg3's first LP started at a weight of 2 686, settled at 2.7 six restarts later and took 744 iterations; with
     // this statistic it starts at 3.2 and takes 220.  64 / 48 / 16 seeds: cfg3 -5.5 %, cfg2 -10 %, cfg4 +4 % (-3 % iterations).
-    static const int omega_robust = std::getenv("KTN_OMEGA_ROBUST") ? std::atoi(std::getenv("KTN_OMEGA_ROBUST")) : 1;
+    const int omega_robust = dev.omega_robust;
     const bool robust = omega_robust && mode == 0 && !have_omega && !row_sharded() && m > 0;
     if (robust) {                                       // log-magnitude statistics of c^ and of the finite row bounds: slots 8..11
         auto logstat = [&](int64_t cnt, const double* a, const double* b, int slot) {
@@ -2559,14 +2608,14 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     double om = (have_omega && mode == 0) ? omega : omega_ref;
     const double rho = 1.0;
     const double cinf_scale = 1.0;
-    if (std::getenv("KTN_DEBUG_LP"))
+    if (dev.debug_lp)
         std::fprintf(stderr, "[lp setup mode %d] m %lld n %lld nnz %lld smax %.4g fro %.4g nc2 %.4g nc2_tol %.4g nb2 %.4g omega_ref %.4g om0 %.4g shift %d b_ref %.9g n_long %lld tol_p %.3g tol_g %.3g\n",
                      mode, (long long)m, (long long)n, (long long)NNZ, smax, fro, nc2, nc2_tol, nb2, omega_ref, om, (int)w_shift, epi_b, (long long)n_long, tol_p, tol_g);
 
     // anchors z0 = z; with the packed records of the plain steps (not for the tiled / row-sharded forms, whose steps are
     // split into SpMV + element-wise kernels)
-    packed_on = !tiled_on && !row_sharded() && NNZ < ((int64_t)1 << 31) && std::getenv("KTN_NO_PACKED") == nullptr;
-    if (const char* pt = std::getenv("KTN_PACKED_TRIPS")) packed_trips = std::atoi(pt);
+    packed_on = !tiled_on && !row_sharded() && NNZ < ((int64_t)1 << 31) && !dev.no_packed;
+    if (dev.packed_trips > 0) packed_trips = dev.packed_trips;
     if (packed_on) {
         d_crec.resize((size_t)n, stream); d_cbl.resize((size_t)n, stream); d_rrec.resize(mm, stream);
         LAUNCH_1(k_pack_cols, n, stream, n, c_ptr.p, ch.p, lh.p, uh.p, xh.p, x0h.p, d_crec.p, d_cbl.p);
@@ -2580,14 +2629,14 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     const double kx_bytes = (double)NNZ * 12 + 8.0 * (n + 1) + 8.0 * 7 * n + 8.0 * m;
     int64_t k = 0, it = 0;
     double r0 = 0.0, r_prev = 0.0;
-    static const bool dbg_lp = std::getenv("KTN_DEBUG_LP") != nullptr;
+    const bool dbg_lp = dev.debug_lp;
     R.status = KTN_STATUS_USERLIMIT;
     const int64_t max_it = lp_iter_budget > 0 ? std::min<int64_t>(lp_iter_budget, prm.lp_max_iter) : prm.lp_max_iter;
     const int chk = std::max(1, prm.lp_check_every);
     const int plain_len = std::min(chk - 1, (int)kMaxChunk);
-    static const int first_chunk = std::getenv("KTN_FIRST_CHUNK") ? std::atoi(std::getenv("KTN_FIRST_CHUNK")) : 31;
+    const int first_chunk = dev.first_chunk;
     bool plain_next = false, near_conv = false, primal_ok = false;
-    static const int stag_chunk = std::getenv("KTN_STAG_CHUNK") ? std::atoi(std::getenv("KTN_STAG_CHUNK")) : 0;
+    const int stag_chunk = dev.stag_chunk;
     // throughput mode: one workgroup per block runs its LP to the end (batch_lp.hpp); the ordinary loop below only serves
     // as the fall-back when a block reports that it could not finish
     bool blocks_done = false;
@@ -2596,7 +2645,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         blocks_done = lp_solve_blocks(tol_p, tol_g, eta, &R, max_it);
         if (blocks_done) it = R.iters;
     }
-    static const int near_env = std::getenv("KTN_NEAR_CHUNK") ? std::atoi(std::getenv("KTN_NEAR_CHUNK")) : -1;
+    const int near_env = dev.near_chunk;
     const int near_chunk = near_env >= 0 ? near_env : prm.lp_near_check;
     while (!blocks_done && it < max_it) {
         const double tau = eta / om, sigma = eta * om;
@@ -2672,12 +2721,12 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
                 //  the third confirmation was 64 more iterations each: -5 ... -7 % PDHG iterations on cfg3 / cfg2 / cfg4 over
                 //  96 / 32 / 8 seeds, objective errors, the 82 reference models, 240 fuzz models and the 48-shape matrix
                 //  unchanged.  KTN_STAG_CHECKS=3 restores the longer window.)
-                static const int stag_checks = std::getenv("KTN_STAG_CHECKS") ? std::atoi(std::getenv("KTN_STAG_CHECKS")) : 2;
+                const int stag_checks = dev.stag_checks;
                 // ("flat" = within 0.4 tol_g; 0.1 until round 3.  The exit decides whether x* is a good separation point, not
                 //  the stop of the ECP loop, and tol_g itself is the accuracy asked of this solve: -12 % PDHG iterations on
                 //  cfg3 over 96 seeds, -9 % on cfg4, cfg2 unchanged, worst objective error 5e-7 of the 1e-6 allowed, the GPU
                 //  suite, fuzz set and shape matrix unchanged.  KTN_FLAT_FACTOR overrides.)
-                static const double flat_f = std::getenv("KTN_FLAT_FACTOR") ? std::atof(std::getenv("KTN_FLAT_FACTOR")) : 0.4;
+                const double flat_f = dev.flat_factor;
                 const double ff = boxed_free ? std::min(flat_f, 0.1) : flat_f;
                 const int nchk = boxed_free ? 3 : stag_checks;
                 const bool flat = std::fabs(pobj - pobj_h[0]) <= ff * tol_g * scale && std::fabs(pobj - pobj_h[1]) <= ff * tol_g * scale &&
@@ -2783,7 +2832,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             const double dx = std::sqrt(dx0sq), dy = std::sqrt(dy0sq);
             if (dbg_lp) std::fprintf(stderr, "[lp restart] it %lld k %lld decayed %d dx %.3e dy %.3e |xt| %.3e |yt| %.3e om %.4g\n", (long long)it, (long long)k, (int)decayed, dx, dy, std::sqrt(xt2), std::sqrt(yt2), om);
             // guarded primal-weight update (oracle/pdlp_mirror.py solve_lp_halpern)
-            static const int om_art = std::getenv("KTN_OMEGA_ART") ? std::atoi(std::getenv("KTN_OMEGA_ART")) : 1;
+            const int om_art = dev.omega_art;
             // Unearned restarts carry little information about the weight (round 4).  The update reads the ratio
             // of the two movements since the last restart.  A solve's first restarts come "by the clock" (k >= 0.36 it: at the
             // first check of every solve, after 32 iterations), whether or not the residual has moved.  After a warm start whose
@@ -2795,15 +2844,14 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             // informative: cfg3 13 -> 36-85 cutting-plane rounds, profiles/r04_omega_ab.txt.)  Instead the weight of the new
             // ratio in the geometric mean grows with the length of the period it was measured over: theta = 0.5 min(1, k / K)
             // for a restart the residual did not earn (K = KTN_OMEGA_ART_K, 0 = the plain 0.5), 0.5 for an earned one.
-            static const double om_art_k = std::getenv("KTN_OMEGA_ART_K") ? std::atof(std::getenv("KTN_OMEGA_ART_K")) : 256.0;
-            static const double om_art_clamp = std::getenv("KTN_OMEGA_ART_CLAMP") ? std::atof(std::getenv("KTN_OMEGA_ART_CLAMP")) : 0.0;
+            const double om_art_k = dev.omega_art_k, om_art_clamp = dev.omega_art_clamp;
             if ((om_art || decayed) && dx > 1e-8 * (1.0 + std::sqrt(xt2)) && dy > 1e-8 * (1.0 + std::sqrt(yt2))) {
-                static const double om_clamp = std::getenv("KTN_OMEGA_CLAMP") ? std::atof(std::getenv("KTN_OMEGA_CLAMP")) : 0.0;
+                const double om_clamp = dev.omega_clamp;
                 const double om_old = om;
                 const double theta = (!decayed && om_art_k > 0.0) ? 0.5 * std::min(1.0, (double)k / om_art_k) : 0.5;
                 om = std::exp(theta * std::log(dy / dx) + (1.0 - theta) * std::log(om));
                 if (!decayed && om_art_clamp > 1.0) om = std::min(std::max(om, om_old / om_art_clamp), om_old * om_art_clamp);
-                static const double om_clamp_dn = std::getenv("KTN_OMEGA_CLAMP_DOWN") ? std::atof(std::getenv("KTN_OMEGA_CLAMP_DOWN")) : 0.0;
+                const double om_clamp_dn = dev.omega_clamp_down;
                 if (om_clamp > 1.0) om = std::min(std::max(om, om_old / om_clamp), om_old * om_clamp);
                 if (om_clamp_dn > 1.0) om = std::max(om, om_old / om_clamp_dn);
                 om = std::min(std::max(om, omega_ref * 1e-3), omega_ref * 1e3);
@@ -2873,7 +2921,7 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
     // LPs beyond the caches: tiled copies of A^ and A^' (kernels.hpp "tiled SpMV") serve the plain steps and the check
     // iterations; the power iteration keeps the CSR / CSC kernels
     {
-        static const char* tenv = std::getenv("KTN_TILED");
+        const bool tenv = dev.tiled >= 0;
         // ... and dense enough: every (tile, block) unit stages a 64 KB block of the input vector, so a matrix with few entries
         // per unit pays more for the staging than for its entries (n = 1e6, 5.8e6 entries: 350 per unit, 1.31 s tiled against
         // 0.49 s with the CSR kernels; cfg4: 9 500 per unit)
@@ -2881,7 +2929,7 @@ void Engine::pdhg_raw(const double* x0, const double* y0, double eta, double ome
         const int64_t units_tt = ceil_div(n_lp, (int64_t)kTileOut) * ceil_div(M, (int64_t)kTileIn);
         tiled_on = prm.lp_tiled_nnz > 0 && NNZ >= prm.lp_tiled_nnz && n_lp >= 2 * kTileIn && M >= 2 * kTileIn &&
                    NNZ >= 4096 * std::max(units_t, units_tt);
-        if (tenv) tiled_on = std::atoi(tenv) != 0 && M > 0 && NNZ > 0;
+        if (tenv) tiled_on = dev.tiled != 0 && M > 0 && NNZ > 0;
         if (tiled_on) {
             auto tt = std::chrono::steady_clock::now();
             tiled_on = build_tiled(tA, M, n_lp, lp_rowptr.p, lp_col.p, r_sval.p, kLongRow) &&
@@ -3701,7 +3749,7 @@ int ktn_dist_init_rccl(ktn_handle h, const char* uid128, int32_t rank, int32_t w
         KTN_REQUIRE(!e->loaded, "ktn_dist_init_*: call before loadproblem");
         KTN_REQUIRE(uid128 && world >= 1 && rank >= 0 && rank < world, "ktn_dist_init_rccl: bad rank / world");
         e->dist.rank = rank; e->dist.world = world;
-        e->dist.force = world == 1 && std::getenv("KTN_FORCE_COLLECTIVE") != nullptr;
+        e->dist.force = world == 1 && e->dev.force_collective;
         if (world > 1 || e->dist.force) {
             ncclUniqueId id;
             std::memcpy(id.internal, uid128, 128);
@@ -3776,8 +3824,7 @@ int ktn_dist_init_ipc(ktn_handle h, int32_t rank, int32_t world, const char* all
         }
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
-        const char* ts = std::getenv("KTN_IPC_TIMEOUT_S");
-        const double secs = ts ? std::atof(ts) : 20.0;
+        const double secs = e->dev.ipc_timeout_s;
         I.timeout_ticks = (long long)(secs * 1e3 * (double)khz);
         I.epoch = 0;
         I.on = true;

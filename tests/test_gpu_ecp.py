@@ -501,3 +501,21 @@ def test_shared_column_model_solves_through_the_long_column_path():
     om = oracle_solve_instance(small)
     assert om.status == "Optimal"
     assert abs(om.getobjval() - ms.getobjval()) <= 2e-6 * max(1.0, abs(om.getobjval()))
+
+
+def test_primal_weight_rule_removes_the_cfg2_seed_92_stall(monkeypatch):
+    """VERDICT r3 item 3, pinned.  cfg2 seed 92 took 1.0 s instead of 0.06 s: a warm start with a converged primal, four restarts
+    "by the clock" that had not reduced the residual, and the primal weight driven 603 -> 0.16 by the ratio of two noise-level
+    movements (two LP solves of 44 000 and 79 000 iterations).  The weight a restart's ratio gets now grows with the length of
+    the period it was measured over (KTN_OMEGA_ART_K = 256: theta = 0.5 min(1, k / 256) for a restart the residual did not earn).
+    Both rules in ONE process -- the development switches are read per handle at ktn_create -- on the failing model."""
+    inst = ktn.instances.make_config("cfg2", seed=92)
+    new = hip_load_instance(ktn, inst)
+    monkeypatch.setenv("KTN_OMEGA_ART_K", "0")                       # the round-3 rule: every restart's ratio with weight 0.5
+    old = hip_load_instance(ktn, inst)
+    monkeypatch.delenv("KTN_OMEGA_ART_K")
+    assert new.optimize() == "Optimal" and old.optimize() == "Optimal"
+    assert_planted_objective(new.getobjval(), inst)
+    assert_planted_objective(old.getobjval(), inst)
+    assert old.stat("pdhg_iters") > 60000                            # the stall is what the old rule does on this model ...
+    assert new.stat("pdhg_iters") < 15000                            # ... and is gone (5 000 - 6 000 iterations, like its neighbours)
