@@ -173,6 +173,16 @@ typedef struct {
                                        "Smooth-face optima")                                                                    */
 } ktn_params;
 
+/* NL-row blocks over several GPUs with a replicated LP: the exchange step of one cutting-plane round.
+ * what = 0: the handle has just swept ITS block of NL rows; its new LP rows are the rows from `first_new_row` on.  The callback
+ *           moves every rank's new rows into every rank's LP in rank order (ktn_lp_pack_rows_dev -> all-gather ->
+ *           ktn_lp_truncate(first_new_row) -> ktn_lp_append_packed_dev per rank) and returns in scalars[0] the number of rows
+ *           appended in total and in scalars[1..n) the MAXIMUM over the ranks of what it found there (largest violation, status
+ *           flags, two values the loop's decisions are taken from);
+ * what = 1: scalars[0..n) are replaced by their SUM over the ranks (the shares of the objective certificate).
+ * Return 0, or non-zero to make the running ktn_* call fail with KTN_E_CALLBACK.  The callback may call ktn_lp_* on the handle. */
+typedef int (*ktn_exchange_cb)(void* user, int32_t what, int64_t first_new_row, double* scalars, int32_t nscalars);
+
 /* The device-evaluable statement of the NLP: replaces the
  * MathProgBase.AbstractNLPEvaluator `d` handed to loadproblem! (src/model.jl:86).
  * Jacobian structure is CSR over the num_constr constraints (what initialize! builds
@@ -345,6 +355,13 @@ int ktn_lp_append_rows_nl(ktn_handle h, int64_t nrows, const int64_t* rowptr, co
 int ktn_lp_pack_rows_dev(ktn_handle h, int64_t first_row, int64_t id_offset, double* dev_out, int64_t cap,
                          int64_t* nrows, int64_t* nnz);
 int ktn_lp_append_packed_dev(ktn_handle h, int64_t nrows, int64_t nnz, const double* dev_in);
+/* ONE implementation of the cutting-plane step for the NL-row-block layout (round 4): with an exchange callback installed
+ * (after ktn_lp_enable_global_lists; first_nl_id = global id of this handle's first NL row) ktn_ecp_step / ktn_optimize run the
+ * engine's own loop -- tolerance schedule, floor rule, purge, refinement by the objective certificate -- and call the callback
+ * where the single-GPU loop sweeps: every decision of the loop is taken from what the callback returns, i.e. from the same
+ * numbers on every rank.  (Until round 3 a host loop re-stated those rules on top of the building blocks above.)  cb = NULL
+ * removes it. */
+int ktn_set_cut_exchange(ktn_handle h, ktn_exchange_cb cb, void* user, int64_t first_nl_id);
 /* cut-pool purge after an LP solve (what ktn_ecp_step does between the LP and the sweep); deterministic, so ranks that
  * hold identical LPs stay identical */
 int ktn_lp_purge(ktn_handle h, int64_t* rows_removed);

@@ -42,6 +42,8 @@ class KtnNlpDesc(C.Structure):
 # ktn_eval_rows_cb / ktn_eval_obj_cb (include/katana_hip.h)
 EVAL_ROWS_CB = C.CFUNCTYPE(c_i32, C.c_void_p, P(c_f64), P(c_f64), P(c_f64))
 EVAL_OBJ_CB = C.CFUNCTYPE(c_i32, C.c_void_p, P(c_f64), P(c_f64), P(c_f64))
+# ktn_exchange_cb: (user, what, first_new_row, scalars, nscalars)
+EXCHANGE_CB = C.CFUNCTYPE(c_i32, C.c_void_p, c_i32, c_i64, P(c_f64), c_i32)
 
 
 ALLREDUCE_CB = C.CFUNCTYPE(c_i32, C.c_void_p, P(c_f64), c_i64, c_i32)
@@ -98,6 +100,7 @@ PROTOTYPES = {
     "ktn_lp_append_packed_dev": (c_i32, [C.c_void_p, c_i64, c_i64, C.c_void_p]),
     "ktn_lp_purge": (c_i32, [C.c_void_p, P(c_i64)]),
     "ktn_lp_enable_global_lists": (c_i32, [C.c_void_p, c_i64]),
+    "ktn_set_cut_exchange": (c_i32, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64]),
     "ktn_last_sweep_slots": (c_i32, [C.c_void_p, P(c_i64), c_i64, P(c_i64)]),
     "ktn_lp_append_rows_nl": (c_i32, [C.c_void_p, c_i64, P(c_i64), P(c_i32), P(c_f64), P(c_f64), P(c_f64), P(c_i64)]),
     "ktn_set_blocks": (c_i32, [C.c_void_p, c_i64, P(c_i64)]),

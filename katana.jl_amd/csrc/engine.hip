@@ -281,6 +281,12 @@ struct Engine {
     // of an iteration that found every row satisfied) reuses the scaling, the tiled copies and the sigma_max estimate.
     uint64_t lp_version = 1, scaled_version = 0, smax_version = 0;
     bool scaled_identity = false;
+    // NL-row blocks over several GPUs with a replicated LP (the north star's design): the caller's callback exchanges the cuts of
+    // a sweep (ktn_set_cut_exchange); the cutting-plane loop itself -- floor rule, refinement, certificate -- stays Engine::step
+    ktn_exchange_cb exch_cb = nullptr;
+    void* exch_user = nullptr;
+    int64_t exch_lo = 0;         // global id of this handle's first NL row
+    bool exchanging() const { return exch_cb != nullptr; }
     bool sharded_rows = false;   // rows were appended/truncated from the host: cut lists are not tracked ...
     bool glists = false;         // ... unless the host supplies global NL-row ids (ktn_lp_enable_global_lists)
     int64_t nl_total = 0;
@@ -428,6 +434,7 @@ struct Engine {
     DBuf<double> d_cert;
     double objective_certificate(int64_t id_offset = 0, bool raw = false);
     double certificate_all_ranks();
+    bool sweep_all(const double* d_x, double f_cut, bool lp_ok, int lp_stat, int64_t* nviol, double* maxviol, double* extra0, double* extra1);
     double certificate_blocks(double* gap_tol);
     DBuf<double> d_certblk;
     double best_viol = kInf, best_obj = 0.0;
@@ -2848,7 +2855,9 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             if ((om_art || decayed) && dx > 1e-8 * (1.0 + std::sqrt(xt2)) && dy > 1e-8 * (1.0 + std::sqrt(yt2))) {
                 const double om_clamp = dev.omega_clamp;
                 const double om_old = om;
-                const double theta = (!decayed && om_art_k > 0.0) ? 0.5 * std::min(1.0, (double)k / om_art_k) : 0.5;
+                // (models with free variables run inside the box the presolve put around them and keep the round-3 rule, like their
+                //  exit rules above: fuzz model 2/109 ends `:Error` -- a cut taken 1e13 from the origin -- under the damped update)
+                const double theta = (!decayed && om_art_k > 0.0 && !has_inf_bound) ? 0.5 * std::min(1.0, (double)k / om_art_k) : 0.5;
                 om = std::exp(theta * std::log(dy / dx) + (1.0 - theta) * std::log(om));
                 if (!decayed && om_art_clamp > 1.0) om = std::min(std::max(om, om_old / om_art_clamp), om_old * om_art_clamp);
                 const double om_clamp_dn = dev.omega_clamp_down;
@@ -3088,14 +3097,21 @@ void Engine::step(int32_t* done) {
     double tol_g = std::min(std::max(tol_p, prm.lp_gap_floor), prm.lp_gap_cap);
     LpResult R = lp_solve(tol_p, tol_g, 0);
     lp_status = R.status;
-    if (R.status != KTN_STATUS_OPTIMAL) { status = R.status; return; }   // model.jl:261-263
-    if (prm.vis_data) lp_sols.push_back(lp_x.to_host(stream));          // model.jl:267
-    if (prm.purge_age > 0 && !prm.vis_data && !sharded_rows && M - M_base >= std::max<int64_t>(prm.purge_min_rows, 1)) purge_cuts();
     int64_t nviol = 0;
-    double mv = 0.0;
-    bool nonfin = false;
-    global_sweep(lp_x.p, prm.f_tol, &nviol, &mv, &nonfin);               // model.jl:268-283
-    if (nonfin) { status = KTN_STATUS_ERROR; return; }
+    double mv = 0.0, ex_not_floor = 0.0, ex_obj = objval;
+    if (R.status != KTN_STATUS_OPTIMAL) {                                // model.jl:261-263
+        // (NL-row blocks: a rank whose LP failed still takes part in this iteration's exchange -- its flag makes every rank leave)
+        if (exchanging()) (void)sweep_all(lp_x.p, prm.f_tol, false, R.status, &nviol, &mv, &ex_not_floor, &ex_obj);
+        status = R.status;
+        return;
+    }
+    if (prm.vis_data) lp_sols.push_back(lp_x.to_host(stream));          // model.jl:267
+    // (NL-row blocks: every rank holds the identical LP, so the purge is identical too)
+    if (prm.purge_age > 0 && !prm.vis_data && (!sharded_rows || exchanging()) && M - M_base >= std::max<int64_t>(prm.purge_min_rows, 1)) purge_cuts();
+    const double floor_p0 = prm.lp_tol_floor * prm.f_tol, floor_g0 = std::min(std::max(floor_p0, prm.lp_gap_floor), prm.lp_gap_cap);
+    ex_not_floor = (R.row_viol <= floor_p0 && R.dres_rel <= floor_g0 &&
+                    (R.gap <= floor_g0 || (R.stag_exit && prm.lp_stag_factor > 0.0 && R.gap <= prm.lp_stag_factor * floor_g0))) ? 0.0 : 1.0;
+    if (sweep_all(lp_x.p, prm.f_tol, true, R.status, &nviol, &mv, &ex_not_floor, &ex_obj)) return;      // model.jl:268-283 (true: status set, leave)
     last_maxviol = mv;
     stats["last_maxviol"] = mv; stats["last_nviol"] = (double)nviol;
     const bool sat_now = (nviol == 0);
@@ -3105,8 +3121,8 @@ void Engine::step(int32_t* done) {
     const double floor_g = std::min(std::max(floor_p, prm.lp_gap_floor), prm.lp_gap_cap);
     // (... or ended through the stagnation exit with a gap the floor-tolerance solve would accept through that same exit: it
     //  would return after its first two checks with this very point -- 34 iterations and a setup on cfg3)
-    const bool at_floor = R.row_viol <= floor_p && R.dres_rel <= floor_g &&
-                          (R.gap <= floor_g || (R.stag_exit && prm.lp_stag_factor > 0.0 && R.gap <= prm.lp_stag_factor * floor_g));
+    (void)floor_g;
+    const bool at_floor = ex_not_floor == 0.0;          // (NL-row blocks: the ranks' verdicts agree; taken from the exchange all the same)
     if (sat_now && !R.exact && tol_p > floor_p * (1.0 + 1e-12) && !at_floor) last_maxviol = 0.0;
     else { allsat = sat_now; if (sat_now && tol_p > floor_p * (1.0 + 1e-12) && !R.exact) stats["floor_resolves_skipped"] += 1.0; }
     const double obj = objval;                                           // model.jl:287-289
@@ -3135,7 +3151,7 @@ void Engine::step(int32_t* done) {
     bool refine = false;
     // (row-sharded LP: every rank holds the cut lists of its own NL rows, so the certificate is the all-reduced sum of the ranks'
     //  shares and every decision below is taken from all-reduced numbers: all ranks refine, or none)
-    if (allsat && !eps_stop && !polish_done && !sharded_rows && prm.polish_max_iter > 0 && m_nl_global > 0) {
+    if (allsat && !eps_stop && !polish_done && (!sharded_rows || exchanging()) && prm.polish_max_iter > 0 && (m_nl_global > 0 || exchanging())) {
         if (n_lp <= prm.polish_max_var && !row_sharded()) {
             refine = prm.polish_factor > 0.0 && prm.polish_factor < 1.0;
             polish_phi = prm.polish_factor;
@@ -3145,8 +3161,8 @@ void Engine::step(int32_t* done) {
             // stop rule leaves open; the LP's own accuracy is its gap tolerance) exceeds half the objective tolerance.
             // (A fused batch -- ktn_set_blocks -- owes the tolerance to EVERY instance: D is then the largest per-instance
             //  certificate in units of that instance's target, and the target is 1.)
-            const double target = n_blocks > 0 ? 1.0 : prm.obj_cert_tol * std::max(1.0, std::fabs(objval));
-            cert_gap = 0.25 * target / (1.0 + 2.0 * std::fabs(objval));
+            const double target = n_blocks > 0 ? 1.0 : prm.obj_cert_tol * std::max(1.0, std::fabs(ex_obj));
+            cert_gap = 0.25 * target / (1.0 + 2.0 * std::fabs(ex_obj));
             const double D = n_blocks > 0 ? certificate_blocks(&cert_gap) : certificate_all_ranks();
             stats["cert_evals"] += 1.0;
             stats["cert_last"] = D;
@@ -3195,10 +3211,10 @@ void Engine::polish_step(int32_t* done) {
         *done = 1;
     };
     *done = 0;
+    double ex0 = 0.0, ex1 = 0.0;
     if (polish_count == 0) {
         // first pass: measure (and cut at) the point that met the stop rule
-        global_sweep(lp_x.p, f_eff, &nviol, &mv, &nonfin);
-        if (nonfin) { status = KTN_STATUS_ERROR; polishing = false; *done = 1; return; }
+        if (sweep_all(lp_x.p, f_eff, true, KTN_STATUS_OPTIMAL, &nviol, &mv, &ex0, &ex1)) { polishing = false; *done = 1; return; }
         consider(mv);
         polish_count = 1;
         if (nviol == 0 && cert_target <= 0.0) finish();     // (certificate mode: the LP itself may be what is short -- solve it tighter)
@@ -3213,9 +3229,13 @@ void Engine::polish_step(int32_t* done) {
     const double tol_g = cert_target > 0.0 ? std::min(std::min(std::max(tol_p, prm.lp_gap_floor), prm.lp_gap_cap), cert_gap)
                                            : std::max(prm.lp_gap_floor * polish_phi, 1e-12);
     LpResult R = lp_solve(tol_p, tol_g, 0);
-    if (R.status != KTN_STATUS_OPTIMAL) { finish(); return; }            // keep the point that met the stop rule
-    global_sweep(lp_x.p, f_eff, &nviol, &mv, &nonfin);
-    if (nonfin) { finish(); return; }
+    if (R.status != KTN_STATUS_OPTIMAL) {                                // keep the point that met the stop rule
+        // (NL-row blocks: the exchange of this pass still takes place, so that no rank waits in a collective the others left)
+        if (exchanging()) { const int keep = status; (void)sweep_all(lp_x.p, f_eff, false, R.status, &nviol, &mv, &ex0, &ex1); status = keep; }
+        finish();
+        return;
+    }
+    { const int keep = status; if (sweep_all(lp_x.p, f_eff, true, KTN_STATUS_OPTIMAL, &nviol, &mv, &ex0, &ex1)) { status = keep; finish(); return; } }
     consider(mv);
     if (cert_target > 0.0 && mv <= prm.f_tol) {                          // certificate mode: done as soon as the bound holds
         double gap_now = 0.0;
@@ -3267,7 +3287,37 @@ double Engine::certificate_blocks(double* gap_tol) {
 
 // The certificate of a solve whose NL rows (and their cut lists) are spread over the ranks of a row-sharded LP: the signed shares
 // add up, the sum is clamped -- every rank gets the same number
+// The stop rule's sweep in whichever form the handle runs: alone (sweep), row-sharded LP (all-reduced counts), or NL-row blocks
+// with a replicated LP -- then this rank sweeps its block, the callback moves every rank's new rows into every rank's LP in rank
+// order and returns the totals and the maxima of the flags.  Returns true when the loop has to end (status is set).
+bool Engine::sweep_all(const double* d_x, double f_cut, bool lp_ok, int lp_stat, int64_t* nviol, double* maxviol, double* extra0, double* extra1) {
+    bool nonfin = false;
+    if (!exchanging()) {
+        global_sweep(d_x, f_cut, nviol, maxviol, &nonfin);
+        if (nonfin) { status = KTN_STATUS_ERROR; return true; }
+        return false;
+    }
+    const int64_t m0 = M;
+    int64_t nv = 0;
+    double mv = 0.0;
+    if (lp_ok) sweep(d_x, f_cut, &nv, &mv, &nonfin);
+    double sc[5] = {0.0, mv, (lp_ok ? 0.0 : 2.0) + (nonfin ? 1.0 : 0.0), *extra0, *extra1};
+    if (exch_cb(exch_user, 0, m0, sc, 5) != 0) throw Error(KTN_E_CALLBACK, "cut-exchange callback failed");
+    *nviol = (int64_t)(sc[0] + 0.5);
+    *maxviol = sc[1];
+    *extra0 = sc[3]; *extra1 = sc[4];
+    if (sc[2] >= 2.0) { status = lp_ok ? KTN_STATUS_ERROR : lp_stat; return true; }     // some rank's LP failed
+    if (sc[2] >= 1.0) { status = KTN_STATUS_ERROR; return true; }                        // some rank's sweep met a non-finite cut
+    return false;
+}
+
 double Engine::certificate_all_ranks() {
+    if (exchanging()) {                                  // NL-row blocks: the ranks' shares through the callback (sum)
+        double D = objective_certificate(exch_lo, true);
+        if (!(D == D)) D = kInf;
+        if (exch_cb(exch_user, 1, 0, &D, 1) != 0) throw Error(KTN_E_CALLBACK, "cut-exchange callback failed");
+        return (D == D) ? std::max(D, 0.0) : kInf;
+    }
     if (!row_sharded()) return objective_certificate();
     double D = objective_certificate(0, true);
     if (!(D == D)) D = kInf;
@@ -3684,6 +3734,15 @@ int ktn_last_sweep_slots(ktn_handle h, int64_t* slots, int64_t cap, int64_t* cou
         return KTN_OK;
     })
 }
+int ktn_set_cut_exchange(ktn_handle h, ktn_exchange_cb cb, void* user, int64_t first_nl_id) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(e->loaded && first_nl_id >= 0, "ktn_set_cut_exchange: after loadproblem");
+        KTN_REQUIRE(cb == nullptr || e->glists, "ktn_set_cut_exchange: enable the global cut lists first (ktn_lp_enable_global_lists)");
+        e->exch_cb = cb; e->exch_user = user; e->exch_lo = first_nl_id;
+        return KTN_OK;
+    })
+}
 int ktn_lp_purge(ktn_handle h, int64_t* rows_removed) {
     KTN_TRY(h, {
         Engine* e = h->eng;
@@ -3933,6 +3992,9 @@ int ktn_lp_pack_rows_dev(ktn_handle h, int64_t first_row, int64_t id_offset, dou
         if (!dev_out) return KTN_OK;                                   // size query
         KTN_REQUIRE(cap >= 4 * nr + 2 * nz, "pack_rows_dev: buffer too small");
         const bool ids = e->last_sweep_cuts == nr && nr > 0;          // the rows of the last sweep carry their NL slot
+        // (with global cut lists a row packed WITHOUT its id would silently drop out of dual inheritance, list-based purging and
+        //  the objective certificate on every rank)
+        KTN_REQUIRE(ids || nr == 0 || !e->glists, "pack_rows_dev: the rows from first_row on are not exactly the cuts of the last sweep");
         LAUNCH_1(k_pack_rows, std::max(nr, nz), e->stream, nr, nz, e->lp_rowptr.p + first_row, e->lp_col.p + base, e->lp_val.p + base,
                  e->lp_lo.p + first_row, e->lp_hi.p + first_row, ids ? (const int32_t*)e->d_violslots.p : (const int32_t*)nullptr,
                  id_offset, dev_out);

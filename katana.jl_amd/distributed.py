@@ -180,183 +180,83 @@ class ShardedKatanaModel:
         self.exchange_device = exchange_device
         self.num_var = self.m.num_var
         self._reset_state()
+        from . import _lib as L
+        import weakref
+        me = weakref.ref(self)                                     # (no reference cycle model -> callback -> model: the engine
+                                                                   #  handle is destroyed when the last user reference goes)
+
+        def trampoline(user, what, first_new_row, scalars, nscalars):
+            obj = me()
+            return obj._exchange(user, what, first_new_row, scalars, nscalars) if obj is not None else 1
+        self._cb = L.EXCHANGE_CB(trampoline)                       # kept alive with the model
+        self.m.set_cut_exchange(self._cb, self.shard_lo)
 
     def _reset_state(self):
-        self.iter, self.allsat, self._status, self.last_maxviol = 0, False, "None", 1e300
         self.exchanged_rows = 0
-        self.purged_rows = 0
-        # terminal refinement (Engine::step / polish_step, mirrored): state, the best point so far, the answer once finished
-        self._refining, self._refined, self._phi, self._cert_target, self._pcount = False, False, 1.0, 0.0, 0
-        self._best, self._final = None, None
-        self.cert_refinements, self.polish_iters = 0, 0
 
     def reset(self):
         self.m.reset()
         self._reset_state()
 
+    # ---- the exchange step of one cutting-plane round: what Engine::step calls where the single-GPU loop sweeps ------------
+    def _exchange(self, user, what, first_new_row, scalars, nscalars):
+        """ktn_exchange_cb (include/katana_hip.h).  what = 0: this rank's engine has just swept its block of NL rows; its new LP
+        rows are the rows from `first_new_row` on.  Every rank's new rows are appended to every rank's LP in rank order; scalars[0]
+        <- rows appended in total, scalars[1:] <- the maximum over the ranks of what was there (largest violation, status flags,
+        the two values the loop's decisions ride on).  what = 1: scalars <- their sum over the ranks (certificate shares).
+        The loop itself -- tolerance schedule, floor rule, purge, refinement -- is Engine::step on every rank (round 4: one
+        implementation; until round 3 this class re-stated those rules on top of the building blocks)."""
+        try:
+            import os
+            n = int(nscalars)
+            vals = [float(scalars[k]) for k in range(n)]
+            collective = self.dist is not None and (self.world > 1 or bool(os.environ.get("KTN_FORCE_COLLECTIVE")))
+            if what == 1:
+                if collective:
+                    import torch
+                    t = torch.tensor(vals, dtype=torch.float64, device="cuda" if self.dist.get_backend() == "nccl" else "cpu")
+                    self.dist.all_reduce(t)
+                    vals = [float(v) for v in t.tolist()]
+                for k in range(n):
+                    scalars[k] = vals[k]
+                return 0
+            m0 = int(first_new_row)
+            sc = tuple(vals[1:])                                   # (largest violation, flag, extra0, extra1)
+            if self.exchange_device == "cuda" and collective:
+                total, *maxima = exchange_cuts_dev(self.dist, self.m, m0, self.shard_lo, sc)
+            else:
+                if vals[2] < 2.0:
+                    block = tuple(self.m.lp_rows_from(m0)) + (self.shard_lo + self.m.last_sweep_slots(),)
+                else:                                              # this rank's LP failed: an empty block, the flag does the rest
+                    block = (np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0), np.zeros(0),
+                             np.zeros(0, dtype=np.int64))
+                self.m.lp_truncate(m0)
+                blocks, *maxima = exchange_cuts(self.dist, block, self.exchange_device, scalars=sc)
+                total = 0
+                if maxima[1] < 2.0:
+                    for rp, col, val, lo, hi, ids in blocks:       # rank order => identical LP everywhere
+                        self.m.lp_append_rows(rp, col, val, lo, hi, ids)
+                        total += len(lo)
+            self.exchanged_rows += total
+            scalars[0] = float(total)
+            for k, v in enumerate(maxima):
+                scalars[1 + k] = float(v)
+            return 0
+        except Exception as e:                                     # never raise across the C ABI
+            import sys
+            print("cut-exchange callback failed: %r" % (e,), file=sys.stderr, flush=True)
+            return 1
+
     def optimize_begin(self):
         self.m.optimize_begin()          # box-bounded shards: no presolve work, starts the solve timer
 
-    def _sweep_and_exchange(self, f_cut, lp_ok=True, lp_status="Optimal", purge=False, extra=(0.0, 0.0)):
-        """every rank sweeps its block of NL rows at the LP point (rows beyond f_cut get a cut), the cuts of all ranks are
-        appended in rank order.  Returns (cuts appended, largest violation, leave, max over the ranks of each `extra`): `leave` =
-        some rank's LP or sweep failed and the status is set -- every rank sees the same flags and leaves in the same
-        iteration.  `extra`: two more floats whose maxima ride along (every decision of the loop is taken from quantities that
-        are the same on all ranks by construction, not merely by the determinism of identical LPs on identical GPUs)."""
-        m0 = self.m.lp_num_rows()
-        import os
-        device_resident = (self.exchange_device == "cuda" and self.dist is not None and
-                           (self.world > 1 or bool(os.environ.get("KTN_FORCE_COLLECTIVE"))))     # (forced: the one-rank RCCL test)
-        block = None
-        if lp_ok:
-            if purge:
-                self.purged_rows += self.m.lp_purge()             # identical LPs => identical purge on every rank
-                m0 = self.m.lp_num_rows()
-            nv_local, mv_local = self.m.sweep_lp_point(f_cut)
-            err_local = self.m.status() == "Error"
-            if not device_resident:
-                block = tuple(self.m.lp_rows_from(m0)) + (self.shard_lo + self.m.last_sweep_slots(),)
-                self.m.lp_truncate(m0)
-        else:                                                     # still take part in this iteration's exchange
-            mv_local, err_local = 0.0, False
-            block = (np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0), np.zeros(0),
-                     np.zeros(0, dtype=np.int64))
-        # Two collectives per iteration.  The status flags ride with the size exchange: every rank must leave the loop in
-        # the same iteration (one that returned early would leave the others waiting in the next collective).
-        flag = (2.0 if not lp_ok else 0.0) + (1.0 if err_local else 0.0)
-        sc = (mv_local, flag) + tuple(extra)
-        if device_resident:
-            nviol, maxviol, flags, *ex = exchange_cuts_dev(self.dist, self.m, m0, self.shard_lo, sc)
-            if flags >= 2.0:
-                self._status = lp_status if not lp_ok else "Error"
-                return 0, maxviol, True, ex
-        else:
-            blocks, maxviol, flags, *ex = exchange_cuts(self.dist, block, self.exchange_device, scalars=sc)
-            if flags >= 2.0:
-                self._status = lp_status if not lp_ok else "Error"
-                return 0, maxviol, True, ex
-            nviol = 0
-            for rp, col, val, lo, hi, ids in blocks:             # rank order => identical LP everywhere
-                self.m.lp_append_rows(rp, col, val, lo, hi, ids)
-                nviol += len(lo)
-        self.exchanged_rows += nviol
-        if flags >= 1.0:
-            self._status = "Error"
-            return nviol, maxviol, True, ex
-        return nviol, maxviol, False, ex
-
-    def _certificate(self):
-        """sum over ALL NL rows of multiplier mass x signed residual (every rank adds its block; one tiny all-reduce), clamped"""
-        import os
-        d = self.m.objective_certificate(self.shard_lo)
-        if self.dist is not None and (self.world > 1 or os.environ.get("KTN_FORCE_COLLECTIVE")):
-            import torch
-            t = torch.tensor([d], dtype=torch.float64, device="cuda" if self.dist.get_backend() == "nccl" else "cpu")
-            self.dist.all_reduce(t)
-            d = float(t.item())
-        return max(d, 0.0) if d == d else float("inf")
-
     def ecp_step(self):
-        """one pass of src/model.jl:258-308 across all ranks; returns True when the loop ends"""
-        if self._refining:
-            return self._refine_step()
-        if self.allsat or self.iter >= self.p["iter_cap"] or self._status in ("Error", "Unbounded"):
-            return True
-        self.iter += 1
-        f_tol = self.p["f_tol"]
-        floor_p = self.tol["floor"] * f_tol
-        tol_p = min(max(self.tol["scale"] * self.last_maxviol, floor_p), self.tol["cap"])
-        tol_g = min(max(tol_p, self.tol["gfloor"]), self.tol["gcap"])
-        lp_status, _ = self.m.lp_solve(tol_p, tol_g)
-        # Engine::step's floor rule: satisfied at a loosely solved LP only counts when that solve already meets the floor
-        # tolerances (or left through the stagnation exit with a gap the floor-tolerance solve would accept the same way)
-        floor_g = min(max(floor_p, self.tol["gfloor"]), self.tol["gcap"])
-        stag = self.m.params.lp_stag_factor
-        gap = self.m.stat("lp_last_gap")
-        at_floor = (self.m.stat("lp_last_row_viol") <= floor_p and self.m.stat("lp_last_dres_rel") <= floor_g and
-                    (gap <= floor_g or (self.m.stat("lp_last_stag_exit") > 0 and stag > 0 and gap <= stag * floor_g)))
-        nviol, maxviol, leave, (not_floor, obj_all) = self._sweep_and_exchange(
-            f_tol, lp_status == "Optimal", lp_status, purge=True, extra=(0.0 if at_floor else 1.0, self.m.getobjval()))
-        if leave:
-            return True
-        at_floor = not_floor == 0.0                                # (the ranks' verdicts agree; taken from the exchange all the same)
-        self.last_maxviol = maxviol
-        if nviol == 0 and tol_p > floor_p * (1 + 1e-12) and not at_floor:
-            self.last_maxviol = 0.0                                # satisfied at a loosely solved LP: tighten first
-        else:
-            self.allsat = nviol == 0
-        # Terminal refinement, as Engine::step decides it: fixed factor for the reference's own small models, the objective
-        # certificate beyond (identical LPs and an all-reduced certificate: every rank takes the same decision)
-        prm = self.m.params
-        if self.allsat and not self._refined and self.iter < self.p["iter_cap"] and prm.polish_max_iter > 0 and self.inst.m_nl > 0:
-            if self.m.num_var <= prm.polish_max_var:
-                if 0.0 < prm.polish_factor < 1.0:
-                    self._refining, self._phi, self._cert_target = True, prm.polish_factor, 0.0
-            elif prm.obj_cert_tol > 0.0:
-                target = prm.obj_cert_tol * max(1.0, abs(obj_all))
-                d = self._certificate()
-                if d > 0.5 * target:
-                    self._refining, self._cert_target = True, target
-                    self._phi = min(max(0.25 * target / d, 0.05), 0.5)
-                    self.cert_refinements += 1
-            if self._refining:
-                self._pcount, self._best = 0, None
-                return False
-        return self.allsat or self.iter >= self.p["iter_cap"]
-
-    def _consider(self, viol):
-        if viol <= self.p["f_tol"] and (self._best is None or viol < self._best[0]):
-            self._best = (viol, self.m.getobjval(), self.m.getsolution())
-
-    def _finish_refinement(self):
-        self._refining, self._refined = False, True
-        if self._best is not None:
-            self._final = self._best[1:]
-        return True
-
-    def _refine_step(self):
-        """Engine::polish_step across the ranks: LP at the refinement tolerance, cuts for every row beyond phi * f_tol; the answer
-        is the point with the smallest violation among those that satisfy the reference's stop rule"""
-        prm, f_tol = self.m.params, self.p["f_tol"]
-        f_eff = self._phi * f_tol
-        if self._pcount == 0:                    # first pass: measure (and cut at) the point that met the stop rule
-            nviol, mv, leave, _ = self._sweep_and_exchange(f_eff)
-            if leave:
-                return True
-            self._consider(mv)
-            self._pcount = 1
-            if nviol == 0 and self._cert_target <= 0.0:
-                return self._finish_refinement()
-            return False
-        if self._pcount > prm.polish_max_iter:
-            return self._finish_refinement()
-        self._pcount += 1
-        self.polish_iters += 1
-        tol_p = self.tol["floor"] * f_eff
-        if self._cert_target > 0.0:
-            tol_g = min(min(max(tol_p, self.tol["gfloor"]), self.tol["gcap"]),
-                        0.25 * self._cert_target / (1.0 + 2.0 * abs(self.m.getobjval())))
-        else:
-            tol_g = max(self.tol["gfloor"] * self._phi, 1e-12)
-        lp_status, _ = self.m.lp_solve(tol_p, tol_g)
-        if lp_status != "Optimal":               # (identical LPs: the same on every rank) keep the point that met the stop rule
-            return self._finish_refinement()
-        nviol, mv, leave, _ = self._sweep_and_exchange(f_eff)
-        if leave:
-            return self._finish_refinement()
-        self._consider(mv)
-        if self._cert_target > 0.0 and mv <= f_tol and self._certificate() <= 0.5 * self._cert_target:
-            return self._finish_refinement()
-        if nviol == 0:
-            return self._finish_refinement()
-        return False
+        """one pass of src/model.jl:258-308 across all ranks (Engine::step on every rank, the exchange through _exchange);
+        returns True when the loop ends"""
+        return self.m.ecp_step()
 
     def optimize_end(self):
-        self.m.optimize_end()
-        if self._status in ("Error", "Unbounded", "UserLimit", "Infeasible"):
-            return self._status
-        self._status = "UserLimit" if self.iter >= self.p["iter_cap"] else "Optimal"
-        return self._status
+        return self.m.optimize_end()
 
     def optimize(self):
         self.optimize_begin()
@@ -365,15 +265,23 @@ class ShardedKatanaModel:
         return self.optimize_end()
 
     # getters of the plugin surface
-    def status(self): return self._status
-    def getobjval(self): return self._final[0] if self._final is not None else self.m.getobjval()
-    def getsolution(self): return self._final[1] if self._final is not None else self.m.getsolution()
+    def status(self): return self.m.status()
+    def getobjval(self): return self.m.getobjval()
+    def getsolution(self): return self.m.getsolution()
     def getsolvetime(self): return self.m.getsolvetime()
-    def numiters(self): return self.iter
+    def numiters(self): return self.m.numiters()
     def numcuts(self): return self.m.numcuts()
     def lp_num_rows(self): return self.m.lp_num_rows()
+    @property
+    def iter(self): return self.m.numiters()
+    @property
+    def purged_rows(self): return int(self.m.stat("purged_rows"))
+    @property
+    def cert_refinements(self): return int(self.m.stat("cert_refinements"))
+    @property
+    def polish_iters(self): return int(self.m.stat("polish_iters"))
     def stat(self, name):
-        return float(getattr(self, name)) if name in ("cert_refinements", "polish_iters") else self.m.stat(name)
+        return float(getattr(self, name)) if name == "exchanged_rows" else self.m.stat(name)
 
 
 # =====================================================================================================================

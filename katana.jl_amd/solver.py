@@ -2,6 +2,7 @@
 src/separators.jl, src/util.jl).  Names, argument meaning and status vocabulary follow the
 reference; indices are 0-based."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -68,13 +69,14 @@ class KatanaNonlinearModel:
         if code != L.KTN_OK:
             raise L.KatanaHipError(code, "ktn_create failed (no MI355X visible? the engine has no CPU path)")
         self._lib = lib
+        self._pid = os.getpid()          # a handle belongs to the process that made it (a forked child must not touch the GPU state)
         self._desc = None
         self.num_var = 0
         self.num_constr = 0
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None) and self._h.value:
+            if getattr(self, "_h", None) and self._h.value and getattr(self, "_pid", None) == os.getpid():
                 self._lib.ktn_destroy(self._h)
                 self._h = C.c_void_p()
         except Exception:
@@ -238,6 +240,11 @@ class KatanaNonlinearModel:
             idp = _p(nl_id, C.c_int64)
         L.check(self._h, self._lib.ktn_lp_append_rows_nl(self._h, nr, _p(rowptr, C.c_int64), _p(colp, C.c_int32), _p(valp),
                                                          _p(lo), _p(hi), idp))
+
+    def set_cut_exchange(self, cb, first_nl_id):
+        """ktn_set_cut_exchange: `cb` is an _lib.EXCHANGE_CB instance the caller keeps alive (None removes it)"""
+        ptr = C.cast(cb, C.c_void_p) if cb is not None else None
+        L.check(self._h, self._lib.ktn_set_cut_exchange(self._h, ptr, None, int(first_nl_id)))
 
     def lp_enable_global_lists(self, nl_total):
         L.check(self._h, self._lib.ktn_lp_enable_global_lists(self._h, int(nl_total)))
