@@ -336,6 +336,18 @@ def main():
             loads.append(time.perf_counter() - tl)
         cold["load_s"] = sorted(loads)[1]
         del m2
+        # ... and what a JuMP user pays per solve (a NEW model, src/model.jl:63-65): a fresh handle in this warm process (~100
+        # device buffers allocated anew; a caching block pool was tried in round 4 and was SLOWER -- 28 against 15 ms -- because
+        # giving a block back needs the device synchronisation hipFree does implicitly, for every buffer)
+        fresh = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            m3 = ktn.NonlinearModel(ktn.KatanaSolver(log_level=0, device=local_rank))
+            m3.loadproblem(inst.n, inst.num_constr, inst.l_var, inst.u_var, inst.l_constr, inst.u_constr, inst.sense, nlp)
+            fresh.append(time.perf_counter() - tl)
+            del m3
+        cold["load_new_handle_s"] = sorted(fresh)[1]
         model.reset()
 
     def barrier():
@@ -599,7 +611,8 @@ def main():
             "wall_to_ftol_s": wall_to_ftol, "ecp_iters_to_ftol": iters_to_ftol, "status": status, "objective": obj,
             "planted_objective": inst.opt_obj, "objective_relerr": abs(obj - inst.opt_obj) / max(1.0, abs(inst.opt_obj)),
             "pdhg_iters_per_step": pdhg_timed / args.steps, "solves_in_timed_region": len(solves),
-            "first_solve_s": cold["first_solve_s"] if cold else None, "load_s": cold["load_s"] if cold else None, "cold": cold,
+            "first_solve_s": cold["first_solve_s"] if cold else None, "load_s": cold["load_s"] if cold else None,
+            "load_new_handle_s": cold["load_new_handle_s"] if cold else None, "cold": cold,
             "job_rate_incl_load": (iters_to_ftol / (cold["load_s"] + wall_to_ftol)) if cold else None,
             "roofline": roofline, "sweep_roofline": sweep_roofline, "sweep_roofline_short_rows": sweep_short,
             "spmv_roofline": spmv_roofline, "stream_ceiling": stream_ceiling,
