@@ -547,11 +547,13 @@ def main():
             dt, dn, db = (sm.stat(k) - b1[k] for k in skeys)
             ach = db / dt / 1e9
             sweep_short = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                           "kernel": "k_sep_sweep (row kernel, several short rows per lane group)",
+                           "kernel": ("k_sep_sweep_batch (batch-blocked: 2 048 rows per workgroup, x* staged through LDS in 64 KB blocks, "
+                                      "kind-uniform entry-parallel evaluation)" if sm.stat("sweep_batched") else
+                                      "k_sep_sweep (row kernel, several short rows per lane group)"),
                            "workload": "cfg4-shaped: n=%d, m_nl=%d exp/log rows, k=%d" % (sinst.n, sinst.m_nl, sinst.meta["k"]),
                            "launches": int(dn), "avg_launch_us": 1e6 * dt / dn, "algorithmic_bytes_per_launch": db / dn,
                            "violated_rows_at_the_point": int(nv2)}
-            with_rocprof(sweep_short, PROFILE_ROUND + "_sweep_short_kernel_stats.csv", "k_sep_sweep")
+            with_rocprof(sweep_short, PROFILE_ROUND + "_sweep_short_kernel_stats.csv", "k_sep_sweep_batch" if sm.stat("sweep_batched") else "k_sep_sweep<")
         del sm, sinst
 
     cpu = None

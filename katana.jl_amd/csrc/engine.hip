@@ -166,6 +166,7 @@ struct DevParams {
     int sweep_rows = 0;            // KTN_SWEEP_ROWS       NL rows per lane group of the sweep (0 = by size)
     int blk_cfg = -1;              // KTN_BLK_CFG          tuning variant of the column-blocked sweep
     int sweep_blocked = -1;        // KTN_SWEEP_BLOCKED    0 = row kernel instead of the column-blocked sweep
+    int sweep_batched = -1;        // KTN_SWEEP_BATCHED    0 = row kernel instead of the batch-blocked sweep for many short rows, 1 = always
     int tiled_wg = 2;              // KTN_TILED_WG         workgroups per CU of k_spmv_tiled
     int ecp_power = 20;            // KTN_ECP_POWER        power passes of the device-side batch loop
     int grp_rows = 0, grp_cols = 0;// KTN_GRP_ROWS / COLS  lanes per LP row / column (0 = by average length)
@@ -192,6 +193,7 @@ struct DevParams {
         no_setup_reuse = flag("KTN_NO_SETUP_REUSE"); debug_lp = flag("KTN_DEBUG_LP"); no_packed = flag("KTN_NO_PACKED");
         force_collective = flag("KTN_FORCE_COLLECTIVE");
         sweep_rows = geti("KTN_SWEEP_ROWS", sweep_rows); blk_cfg = geti("KTN_BLK_CFG", blk_cfg); sweep_blocked = geti("KTN_SWEEP_BLOCKED", sweep_blocked);
+        sweep_batched = geti("KTN_SWEEP_BATCHED", sweep_batched);
         tiled_wg = geti("KTN_TILED_WG", tiled_wg); ecp_power = geti("KTN_ECP_POWER", ecp_power);
         grp_rows = geti("KTN_GRP_ROWS", grp_rows); grp_cols = geti("KTN_GRP_COLS", grp_cols); tiled = geti("KTN_TILED", tiled);
         smax_reuse = getd("KTN_SMAX_REUSE", smax_reuse); power_passes = geti("KTN_POWER_PASSES", power_passes);
@@ -741,6 +743,14 @@ struct Engine {
                 e0 = ev_pool[ea]; e1 = ev_pool[eb];
                 ev_recs.push_back({2, ea, eb, sweep_bytes});
             }
+            if (sb_on) {
+                if (!sb_lds_set) {
+                    KTN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sep_sweep_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSbLds));
+                    sb_lds_set = true;
+                }
+                SbView V{d_sbck.p, d_sbrow.p, d_sbpp.p, d_sbseg.p, sb_nb};
+                hipExtLaunchKernelGGL(k_sep_sweep_batch, dim3((unsigned)sb_batches), dim3(kSbThreads), kSbLds, stream, e0, e1, 0, V, P, d_nlrows.p, m_nl, d_x, n_lp, f_tol, O);
+            } else
             if (R >= 4) LAUNCH_GB_EV(grp_sweep, k_sep_sweep, 4, ceil_div(m_nl, (int64_t)4), stream, e0, e1, P, d_nlrows.p, m_nl, d_x, f_tol, O);
             else if (R >= 2) LAUNCH_GB_EV(grp_sweep, k_sep_sweep, 2, ceil_div(m_nl, (int64_t)2), stream, e0, e1, P, d_nlrows.p, m_nl, d_x, f_tol, O);
             else LAUNCH_G_EV(grp_sweep, k_sep_eval, m_nl, stream, e0, e1, P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O);
@@ -847,6 +857,14 @@ struct Engine {
         *maxviol = mv;
     }
     double sweep_bytes = 0.0;
+    // batch-blocked sweep for many short rows (kernels.hpp k_sep_sweep_batch): the regrouped copy of the NL entries
+    bool sb_on = false;
+    int64_t sb_batches = 0;
+    int sb_nb = 0;
+    bool sb_lds_set = false;
+    DBuf<uint16_t> d_sbck, d_sbrow;
+    DBuf<double2> d_sbpp;
+    DBuf<int64_t> d_sbseg;
 
     // ================================================================ LP ============
     void rebuild_csc();
@@ -1247,6 +1265,48 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
             d_bkind.upload(bkind, stream);
             d_part.resize((size_t)m_nl * blk_nb, stream);
         }
+    }
+    // Many short rows: the batch-blocked copy (kernels.hpp k_sep_sweep_batch).  Built on the host in two counting passes over the
+    // NL entries -- bucket (batch of 2 048 slots, block of 8 192 columns, atom kind), rows ascending inside a bucket because
+    // the slots are visited in order -- 20 B per entry.
+    {
+        d_sbck.release(); d_sbrow.release(); d_sbpp.release(); d_sbseg.release();
+        sb_on = !blk_on && 2 * m_nl >= (int64_t)3 * kSbRows * num_cus && n_tape_nl == 0 && n_host_nl == 0 && (double)nnz_nl / (double)std::max<int64_t>(m_nl, 1) <= 128.0 &&
+                n_lp <= (int64_t)kSbCols * 64;
+        if (dev.sweep_batched == 0) sb_on = false;
+        if (dev.sweep_batched == 1) sb_on = m_nl > 0 && n_tape_nl == 0 && n_host_nl == 0 && n_lp <= (int64_t)kSbCols * 64 && !blk_on;
+        if (sb_on) {
+            sb_nb = ceil_div(n_lp, (int64_t)kSbCols);
+            sb_batches = ceil_div(m_nl, (int64_t)kSbRows);
+            const size_t nbuck = (size_t)sb_batches * sb_nb * 4;
+            std::vector<int64_t> segs(nbuck + 4, 0);
+            for (int64_t si = 0; si < m_nl; ++si) {
+                const int64_t r = h_nlrows[(size_t)si];
+                const size_t base = (size_t)(si / kSbRows) * sb_nb * 4;
+                for (int64_t e = h_rowptr[r]; e < h_rowptr[r + 1]; ++e)
+                    ++segs[base + (size_t)(h_col[e] / kSbCols) * 4 + akind[e] + 1];
+            }
+            for (size_t k = 1; k < segs.size(); ++k) segs[k] += segs[k - 1];
+            std::vector<int64_t> cur(segs.begin(), segs.begin() + nbuck);
+            std::vector<uint16_t> sck((size_t)nnz_nl), srw((size_t)nnz_nl);
+            std::vector<double2> spp((size_t)nnz_nl);
+            for (int64_t si = 0; si < m_nl; ++si) {
+                const int64_t r = h_nlrows[(size_t)si];
+                const size_t base = (size_t)(si / kSbRows) * sb_nb * 4;
+                const uint16_t rl = (uint16_t)(si % kSbRows);
+                for (int64_t e = h_rowptr[r]; e < h_rowptr[r + 1]; ++e) {
+                    const int64_t bl = h_col[e] / kSbCols;
+                    const int64_t w = cur[base + (size_t)bl * 4 + akind[e]]++;
+                    sck[(size_t)w] = (uint16_t)(h_col[e] - bl * kSbCols);
+                    srw[(size_t)w] = rl;
+                    spp[(size_t)w] = make_double2(p0[e], p1[e]);
+                }
+            }
+            segs.resize(nbuck + 1);
+            d_sbck.upload(sck, stream); d_sbrow.upload(srw, stream); d_sbpp.upload(spp, stream); d_sbseg.upload(segs, stream);
+            sync();
+        }
+        stats["sweep_batched"] = sb_on ? 1.0 : 0.0;
     }
     // algorithmic bytes of one evaluation pass over the NL rows (DESIGN.md "sweep bytes")
     sweep_bytes = (double)nnz_nl * (4 + 16) + 8.0 * (m_nl + 1) + 8.0 * n_lp + 8.0 * 4 * m_nl + 16.0 * m_nl;

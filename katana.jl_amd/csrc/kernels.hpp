@@ -312,6 +312,152 @@ __global__ __launch_bounds__(kBlock) void k_sep_sweep(NlpDev P, const int32_t* _
     if (!MAT) block_max_nonneg(O.maxviol, viol);
 }
 
+// ---- batch-blocked sweep for MANY SHORT rows (round 4; cfg4: 1e6 rows of 32 entries) ---------------
+// The row kernel above gathers x*[col] from L2 once per ENTRY: 3.2e7 eight-byte gathers, each its own L1 miss that drags a
+// 128-byte line -- 4 GB of L2->L1 traffic per sweep, which is what bounds it at 19 % of the HBM peak.  A short row cannot be
+// split over column blocks the way k_sep_eval_blk splits long ones (a 32-byte partial per 2.5 entries), and a thread-per-row
+// form with the block of x* in LDS (round 3) ends up FP64-bound at 2.4x the useful work, because exp and log atoms mix inside
+// every wavefront and every lane runs the longest row's entry slots.  This form keeps what both had right:
+//   * a workgroup owns a BATCH of kSbRows consecutive NL slots and keeps their accumulators (g, x.grad g, max, non-finite) in
+//     LDS for the whole pass;
+//   * the batch's entries are regrouped at load time block-major (blocks of kSbCols columns) and, inside a (batch, block)
+//     unit, by atom kind and then by row: 20 B per entry -- 16-bit local column, 16-bit local row, two parameters;
+//   * per unit the workgroup stages 64 KB of x* in LDS ONCE (13 B of L2 traffic per entry instead of 128) and evaluates the
+//     unit's entries ENTRY-parallel in chunks of 1 024: every wavefront runs exactly one atom kind on 64 useful entries;
+//   * the per-entry results go through an LDS scratch; the first lane of every run of equal rows (runs are contiguous: sorted)
+//     adds its run up in storage order and updates the row's accumulator.  Chunks never mix kinds, so a row has at most one
+//     run per chunk and one lane owns it: no atomics, a fixed summation order, bitwise reproducible sweeps.
+constexpr int kSbRows = 2048;
+constexpr int kSbCols = 8192;
+constexpr int kSbThreads = 1024;
+constexpr size_t kSbLds = (size_t)kSbCols * 8 + (size_t)kSbRows * (3 * 8 + 4) + (size_t)kSbThreads * (3 * 8 + 2);
+struct SbView {
+    const uint16_t* ck;      // local column
+    const uint16_t* row;     // local row (NL slot - batch * kSbRows)
+    const double2* pp;       // (p0, p1)
+    const int64_t* seg;      // [(batches * nb + 1) * 4]: first entry of (batch, block, kind); the last slot closes the list
+    int nb;                  // column blocks
+};
+__global__ __launch_bounds__(kSbThreads) void k_sep_sweep_batch(SbView V, NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
+                                                                const double* __restrict__ x, int64_t n_x, double f_tol, SweepOut O) {
+    extern __shared__ double sb_sm[];
+    double* xs = sb_sm;
+    double* acc_g = xs + kSbCols;
+    double* acc_d = acc_g + kSbRows;
+    double* acc_m = acc_d + kSbRows;
+    double* sval = acc_m + kSbRows;
+    double* sxd = sval + kSbThreads;
+    double* sder = sxd + kSbThreads;
+    int32_t* acc_nf = reinterpret_cast<int32_t*>(sder + kSbThreads);
+    uint16_t* srow = reinterpret_cast<uint16_t*>(acc_nf + kSbRows);
+    const int tid = threadIdx.x;
+    const int64_t batch = blockIdx.x, s0 = batch * kSbRows;
+    const int nrows = (int)((m_nl - s0) < kSbRows ? (m_nl - s0) : kSbRows);
+    __shared__ int64_t sseg[64 * 4 + 1];                           // the batch's segment table (nb <= 64 blocks)
+    for (int i = tid; i < kSbRows; i += kSbThreads) { acc_g[i] = 0.0; acc_d[i] = 0.0; acc_m[i] = -__builtin_inf(); acc_nf[i] = 0; }
+    const int nseg = V.nb * 4;
+    for (int i = tid; i <= nseg; i += kSbThreads) sseg[i] = V.seg[batch * nseg + i];
+    __syncthreads();
+    // The batch's chunks -- at most kSbThreads entries of ONE (block, kind) segment each -- form one stream; the loads of the
+    // next chunk are issued (into registers) before the current one is evaluated, so the HBM latency of the 20 KB a chunk
+    // reads is covered by a chunk's worth of FP64 work instead of being paid 78 times per batch.  (Measured on cfg4's sweep,
+    // tools/sweep_ab.py: plain 475 us, with this prefetch 398, with the next block of x* requested a chunk ahead 380; letting
+    // the kinds of a unit share chunks -- 17 % fewer chunks, heads added up kind after kind -- 469: the per-lane kind costs
+    // more than the fuller chunks save.  Row kernel: 451.)
+    struct Cur { int sg; int64_t cb, e1; };                         // segment index (block * 4 + kind), chunk start, segment end
+    auto settle = [&](Cur& c) {                                     // skip empty segments
+        while (c.sg < nseg && c.cb >= c.e1) { ++c.sg; if (c.sg < nseg) { c.cb = sseg[c.sg]; c.e1 = sseg[c.sg + 1]; } }
+    };
+    Cur cur{0, sseg[0], sseg[1]}, nxt;
+    settle(cur);
+    int nck = 0; uint16_t nrw = 0xFFFF; double2 npp = make_double2(0.0, 0.0);
+    auto fetch = [&](const Cur& c) {
+        const int64_t e = c.cb + tid;
+        const bool live = c.sg < nseg && e < c.e1;
+        nck = live ? (int)V.ck[e] : 0;
+        nrw = live ? V.row[e] : (uint16_t)0xFFFF;
+        npp = live ? V.pp[e] : make_double2(0.0, 0.0);
+    };
+    fetch(cur);
+    int staged = -1;
+    double xpre[kSbCols / kSbThreads];                              // the NEXT block's slice of x*, requested one chunk ahead
+    int xpre_b = -1;
+    auto xfetch = [&](int b) {
+        const int64_t c0 = (int64_t)b * kSbCols;
+#pragma unroll
+        for (int i = 0; i < kSbCols / kSbThreads; ++i) {
+            const int64_t c = c0 + i * kSbThreads + tid;
+            xpre[i] = c < n_x ? x[c] : 0.0;
+        }
+        xpre_b = b;
+    };
+    if (cur.sg < nseg) xfetch(cur.sg >> 2);
+    while (cur.sg < nseg) {
+        const int b = cur.sg >> 2, kind = cur.sg & 3;
+        if (b != staged) {                                          // a new column block: its 64 KB of x* into LDS, once
+            if (xpre_b != b) xfetch(b);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < kSbCols / kSbThreads; ++i) xs[i * kSbThreads + tid] = xpre[i];
+            staged = b;
+            __syncthreads();
+        }
+        const int ck = nck; const uint16_t rw = nrw; const double2 pp = npp;
+        const bool live = rw != (uint16_t)0xFFFF;
+        nxt = cur; nxt.cb += kSbThreads; settle(nxt);
+        fetch(nxt);                                                 // the next chunk's loads are in flight while this one is evaluated
+        if (nxt.sg < nseg && (nxt.sg >> 2) != b) xfetch(nxt.sg >> 2);   // ... and, on a unit's last chunk, the next block of x*
+        const double xv = xs[ck];
+        double val = 0.0, der = 0.0;
+        if (live) {
+            switch (kind) {                                         // (uniform over the workgroup: a chunk holds one kind)
+                case KTN_ATOM_LIN: atom_eval(KTN_ATOM_LIN, pp.x, pp.y, xv, val, der); break;
+                case KTN_ATOM_QUAD: atom_eval(KTN_ATOM_QUAD, pp.x, pp.y, xv, val, der); break;
+                case KTN_ATOM_EXP: atom_eval(KTN_ATOM_EXP, pp.x, pp.y, xv, val, der); break;
+                default: atom_eval(KTN_ATOM_NEGLOG, pp.x, pp.y, xv, val, der); break;
+            }
+        }
+        sval[tid] = val; sxd[tid] = xv * der; sder[tid] = der; srow[tid] = rw;
+        __syncthreads();
+        if (live && (tid == 0 || srow[tid - 1] != rw)) {            // head of a run of equal rows: add the run up in storage order
+            double g = 0.0, d = 0.0, mx = -__builtin_inf();
+            int nf = 0;
+            for (int j = tid; j < kSbThreads && srow[j] == rw; ++j) {
+                g += sval[j]; d += sxd[j]; mx = nanmax(mx, sder[j]); nf |= !isfinite(sder[j]);
+            }
+            acc_g[rw] += g; acc_d[rw] += d; acc_m[rw] = nanmax(acc_m[rw], mx); acc_nf[rw] |= nf;
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+    __syncthreads();
+    // the isconstrsat tail of k_sep_sweep, one thread per row of the batch
+    double viol = 0.0;
+    for (int i = tid; i < nrows; i += kSbThreads) {
+        const int32_t rr = nl_rows[s0 + i];
+        if (P.row_kind[rr] != KTN_ROW_SEP) continue;
+        const double g = acc_g[i] + P.rconst[rr];
+        double m = acc_m[i];
+        if (P.pad_zero[rr]) m = nanmax(m, 0.0);
+        const int nf = acc_nf[i];
+        O.g[rr] = g;
+        O.bconst[rr] = g - acc_d[i];
+        O.maxc[rr] = m;
+        O.nonfin[rr] = nf;
+        const double lb = P.lb[rr], ub = P.ub[rr];
+        const bool sat = (g >= lb - f_tol) && (g <= ub + f_tol);   // separators.jl:120 (NaN -> violated)
+        O.flag[s0 + i] = sat ? 0 : 1;
+        O.cnt[s0 + i] = sat ? 0 : (P.rowptr[rr + 1] - P.rowptr[rr]);
+        if (!sat) {
+            double v = fmax(g - ub, lb - g);
+            if (v != v) v = __builtin_inf();
+            viol = fmax(viol, v);
+            if (nf) { if (*O.any_nonfin == 0) atomicOr(O.any_nonfin, 1); };
+        }
+    }
+    block_max_nonneg(O.maxviol, viol);
+}
+
 // ---- column-blocked evaluation for LONG rows (HBM-resident Jacobians) ------------------
 // k_sep_eval gathers x*[col] from L2: with thousands of entries per row every 8-byte gather pulls its own 128-byte
 // line into the L1 and the kernel is bound by that traffic at a third of the HBM peak.  For such instances the
