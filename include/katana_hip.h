@@ -417,6 +417,9 @@ int ktn_dist_init_callback(ktn_handle h, int32_t rank, int32_t world, ktn_allred
 int ktn_dist_ipc_export(ktn_handle h, int32_t rank, int32_t world, int64_t capacity, char* out_handles128);
 int ktn_dist_init_ipc(ktn_handle h, int32_t rank, int32_t world, const char* all_handles /* world x 128 bytes */);
 int ktn_dist_allreduce_probe(ktn_handle h, int64_t n, int32_t reps, double* usec_per_call, double* max_abs_err);
+/* leave the peer-buffer transport again (before ktn_loadproblem), e.g. after a failed ktn_dist_allreduce_probe: the handle
+ * can then be given another transport (ktn_dist_init_rccl / _callback) -- decided once, at init, in the same process */
+int ktn_dist_release_ipc(ktn_handle h);
 
 #ifdef __cplusplus
 }

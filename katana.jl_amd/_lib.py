@@ -101,6 +101,7 @@ PROTOTYPES = {
     "ktn_lp_purge": (c_i32, [C.c_void_p, P(c_i64)]),
     "ktn_lp_enable_global_lists": (c_i32, [C.c_void_p, c_i64]),
     "ktn_set_cut_exchange": (c_i32, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64]),
+    "ktn_dist_release_ipc": (c_i32, [C.c_void_p]),
     "ktn_last_sweep_slots": (c_i32, [C.c_void_p, P(c_i64), c_i64, P(c_i64)]),
     "ktn_lp_append_rows_nl": (c_i32, [C.c_void_p, c_i64, P(c_i64), P(c_i32), P(c_f64), P(c_f64), P(c_f64), P(c_i64)]),
     "ktn_set_blocks": (c_i32, [C.c_void_p, c_i64, P(c_i64)]),

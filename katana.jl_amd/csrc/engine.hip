@@ -3862,6 +3862,18 @@ int ktn_dist_unique_id(char* out128) {
     std::memcpy(out128, id.internal, 128);
     return KTN_OK;
 }
+// Leave the peer-buffer transport again (before loadproblem): the handle can then be given another transport.  Used by the
+// probe-at-init policy of the host side: peer buffers only where ktn_dist_allreduce_probe passed on every rank of THIS box.
+int ktn_dist_release_ipc(ktn_handle h) {
+    KTN_TRY(h, {
+        Engine* e = h->eng;
+        KTN_REQUIRE(!e->loaded, "ktn_dist_release_ipc: call before loadproblem");
+        e->ipc_release();
+        e->dist.ipc = decltype(e->dist.ipc)();
+        e->dist.rank = 0; e->dist.world = 1;
+        return KTN_OK;
+    })
+}
 int ktn_dist_init_rccl(ktn_handle h, const char* uid128, int32_t rank, int32_t world) {
     KTN_TRY(h, {
         Engine* e = h->eng;

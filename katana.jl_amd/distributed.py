@@ -341,9 +341,15 @@ class RowShardedKatanaModel:
         import os
         forced = world == 1 and dist is not None and bool(os.environ.get("KTN_FORCE_COLLECTIVE"))   # one-rank RCCL test
         if world > 1 or forced:
+            fallback = "rccl" if dist.get_backend() == "nccl" else "callback"
             if transport == "auto":
-                transport = os.environ.get("KTN_DIST_TRANSPORT") or ("rccl" if dist.get_backend() == "nccl" else "callback")
-            if transport == "ipc":
+                # over RCCL's backend with several GPUs: PROBE -- the peer-buffer transport (an n-vector all-reduce in ~12 us instead
+                # of a 2 (w - 1)-hop ring) where its self-test passes on every rank of this box, RCCL otherwise
+                transport = os.environ.get("KTN_DIST_TRANSPORT") or ("probe" if (dist.get_backend() == "nccl" and world > 1) else fallback)
+            if transport == "probe":
+                transport = "ipc" if self._probe_ipc(C, L, lib, h, inst, rank, world, dist) else fallback
+                self.probe_verdict = transport
+            elif transport == "ipc":
                 # peer-buffer transport (include/katana_hip.h): export this rank's buffers, gather everybody's handles, map them
                 import torch
                 cap = int(inst.n) + 64                       # (+ epigraph column; the scalar reductions need far less)
@@ -359,6 +365,8 @@ class RowShardedKatanaModel:
                 _, err = self.allreduce_probe(min(cap, 1 << 16), 2)
                 if not err <= 1e-9:
                     raise RuntimeError("peer-buffer transport failed its self-test on rank %d: deviation %g" % (rank, err))
+            if transport == "ipc":
+                pass
             elif transport == "rccl":
                 import torch
                 uid = C.create_string_buffer(128)
@@ -375,6 +383,43 @@ class RowShardedKatanaModel:
         self.transport = transport if (world > 1 or forced) else "none"
         s = self.inst
         self.m.loadproblem(s.n, s.num_constr, s.l_var, s.u_var, s.l_constr, s.u_constr, s.sense, SeparableNLP(s))
+
+    def _probe_ipc(self, C, L, lib, h, inst, rank, world, dist):
+        """Try the peer-buffer transport and keep it only if EVERY rank could export, map and pass the self-test
+        (ktn_dist_allreduce_probe: six rounds of changing contents through both slots, sum and max, against values each rank
+        computes itself -- on several GPUs this is the test of the cross-GPU visibility rule the protocol rests on, which one GPU
+        cannot exercise).  Every step is followed by a vote (all-reduce MIN), so all ranks take the same branch; a rank that
+        failed leaves the transport again (ktn_dist_release_ipc) and the caller falls back to RCCL -- decided once, at init,
+        in the same process."""
+        import os
+        import torch
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+        def vote(ok):
+            t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item() > 0.5)
+
+        cap = int(inst.n) + 64
+        mine = C.create_string_buffer(128)
+        ok = lib.ktn_dist_ipc_export(h, rank, world, cap, mine) == 0 and not (os.environ.get("KTN_DIST_PROBE_FAIL") == str(rank))
+        t = torch.tensor(list(mine.raw), dtype=torch.uint8, device=dev)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        if not vote(ok):
+            lib.ktn_dist_release_ipc(h)
+            return False
+        raw = b"".join(bytes(g.cpu().tolist()) for g in got)
+        ok = lib.ktn_dist_init_ipc(h, rank, world, raw) == 0
+        if not vote(ok):
+            lib.ktn_dist_release_ipc(h)
+            return False
+        us, err = C.c_double(0.0), C.c_double(1.0)
+        ok = lib.ktn_dist_allreduce_probe(h, min(cap, 1 << 16), 2, C.byref(us), C.byref(err)) == 0 and err.value <= 1e-9
+        if not vote(ok):
+            lib.ktn_dist_release_ipc(h)
+            return False
+        return True
 
     def __getattr__(self, name):                # getters, stepping interface, stats: those of the local handle
         return getattr(self.m, name)

@@ -473,6 +473,44 @@ def test_two_rank_row_sharded_lp_over_the_peer_buffer_transport():
     assert max_nl_violation(inst, out[0][3]) <= 1e-6 * (1 + 1e-6)
 
 
+def _worker_rowshard_probe(rank, world, port, out, inst_kw, fail_rank):
+    sys.path.insert(0, ROOT)
+    if fail_rank is not None:
+        os.environ["KTN_DIST_PROBE_FAIL"] = str(fail_rank)      # that rank reports a failed export: every rank must fall back
+    import torch.distributed as dist
+    import katana_jl_amd as ktn
+    from katana_jl_amd.distributed import RowShardedKatanaModel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    inst = ktn.instances.make_instance(**inst_kw)
+    m = RowShardedKatanaModel(ktn.KatanaSolver(log_level=0, device=0), inst, rank, world, dist, transport="probe")
+    status = m.optimize()
+    out[rank] = (m.transport, status, m.getobjval(), m.getsolution(), m.allreduce_probe(inst.n, 2)[1])
+    dist.barrier()
+    del m
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail_rank", [None, 1])
+def test_transport_is_chosen_by_the_probe_at_init(fail_rank):
+    """transport = "probe" (what "auto" resolves to over the nccl backend with several GPUs) tries the
+    peer-buffer transport and keeps it only where every rank exported, mapped and passed ktn_dist_allreduce_probe; one rank
+    voting no (here: simulated) makes EVERY rank leave it again (ktn_dist_release_ipc) and take the fallback -- in the same
+    process, decided once, before the problem is loaded.  Either way the solve ends at the planted optimum with the same x."""
+    import katana_jl_amd as ktn
+    from helpers import assert_planted_objective
+    world = 2
+    inst_kw = dict(n=400, m_nl=60, k=10, family="explog", seed=11)
+    out = mp.Manager().dict()
+    mp.spawn(_worker_rowshard_probe, args=(world, _free_port(), out, inst_kw, fail_rank), nprocs=world, join=True)
+    inst = ktn.instances.make_instance(**inst_kw)
+    want = "ipc" if fail_rank is None else "callback"
+    for r in range(world):
+        assert out[r][0] == want and out[r][1] == "Optimal" and out[r][4] <= 1e-12
+    assert out[0][2] == out[1][2] and np.array_equal(out[0][3], out[1][3])
+    assert_planted_objective(out[0][2], inst)
+
+
 @pytest.mark.gpu
 def test_three_rank_row_sharded_solve_over_the_peer_buffer_transport():
     """three processes on cuda:0: more than one peer per rank (the flag words per source, the alternating slots); every rank ends
