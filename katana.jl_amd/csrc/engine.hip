@@ -690,6 +690,8 @@ struct Engine {
         } else {
             LAUNCH_G(grp_sweep, k_sep_eval, m_ext, stream, P, d_allrows.p, m_ext, d_x, 0.0, 1, 0, O);
         }
+        if (n_longev > 0)
+            hipLaunchKernelGGL(k_sep_eval_long, dim3((unsigned)n_longev), dim3(1024), 0, stream, P, d_longev_rows.p, d_longev_slots.p, d_x, 0.0, 0, O);
         LAUNCH_1(k_tape_eval, (int64_t)d_taperows_all.n, stream, P, d_taperows_all.p, (int64_t)d_taperows_all.n, d_x, O);
         if (n_host > 0) host_eval(d_x);
         // cut constants / maxima of tape rows from the materialised Jacobian (flags unused here)
@@ -755,6 +757,8 @@ struct Engine {
             else if (R >= 2) LAUNCH_GB_EV(grp_sweep, k_sep_sweep, 2, ceil_div(m_nl, (int64_t)2), stream, e0, e1, P, d_nlrows.p, m_nl, d_x, f_tol, O);
             else LAUNCH_G_EV(grp_sweep, k_sep_eval, m_nl, stream, e0, e1, P, d_nlrows.p, m_nl, d_x, f_tol, 0, 1, O);
         }
+        if (n_longev_nl > 0)
+            hipLaunchKernelGGL(k_sep_eval_long, dim3((unsigned)n_longev_nl), dim3(1024), 0, stream, P, d_longev_nlrows.p, d_longev_nlslots.p, d_x, f_tol, 1, O);
         if (n_tape_nl > 0 || n_host_nl > 0) {
             LAUNCH_1(k_tape_eval, n_tape_nl, stream, P, d_taperows_nl.p, n_tape_nl, d_x, O);
             if (n_host_nl > 0) host_eval(d_x);
@@ -857,6 +861,10 @@ struct Engine {
         *maxviol = mv;
     }
     double sweep_bytes = 0.0;
+    // very long separable rows (kernels.hpp k_sep_eval_long): all of them / those among the NL rows, with their NL slot
+    DBuf<int32_t> d_longev_rows, d_longev_nlrows;
+    DBuf<int64_t> d_longev_slots, d_longev_nlslots;
+    int64_t n_longev = 0, n_longev_nl = 0;
     // batch-blocked sweep for many short rows (kernels.hpp k_sep_sweep_batch): the regrouped copy of the NL entries
     bool sb_on = false;
     int64_t sb_batches = 0;
@@ -1264,6 +1272,27 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
             d_bseg.upload(bseg, stream);
             d_bkind.upload(bkind, stream);
             d_part.resize((size_t)m_nl * blk_nb, stream);
+        }
+    }
+    // Very long separable rows get the device-side kind kRowSepLong and their own kernel (kernels.hpp k_sep_eval_long) -- not under
+    // the column-blocked sweep, which is the long-row path of the NL rows and reads the host-side kinds
+    {
+        std::vector<uint8_t> dk(h_rowkind);
+        std::vector<int32_t> lr, lnr;
+        std::vector<int64_t> ls, lns;
+        std::vector<int64_t> slot_of((size_t)m_ext, -1);
+        for (int64_t si = 0; si < m_nl; ++si) slot_of[(size_t)h_nlrows[(size_t)si]] = si;
+        for (int64_t i = 0; i < m_ext && !blk_on; ++i) {
+            if (h_rowkind[i] != KTN_ROW_SEP || h_rowptr[(size_t)i + 1] - h_rowptr[(size_t)i] <= kLongEval) continue;
+            dk[(size_t)i] = kRowSepLong;
+            lr.push_back((int32_t)i); ls.push_back(slot_of[(size_t)i]);
+            if (slot_of[(size_t)i] >= 0) { lnr.push_back((int32_t)i); lns.push_back(slot_of[(size_t)i]); }
+        }
+        n_longev = (int64_t)lr.size(); n_longev_nl = (int64_t)lnr.size();
+        if (n_longev > 0) {
+            d_rowkind.upload(dk, stream);
+            d_longev_rows.upload(lr, stream); d_longev_slots.upload(ls, stream);
+            d_longev_nlrows.upload(lnr, stream); d_longev_nlslots.upload(lns, stream);
         }
     }
     // Many short rows: the batch-blocked copy (kernels.hpp k_sep_sweep_batch).  Built on the host in two counting passes over the

@@ -312,6 +312,57 @@ __global__ __launch_bounds__(kBlock) void k_sep_sweep(NlpDev P, const int32_t* _
     if (!MAT) block_max_nonneg(O.maxviol, viol);
 }
 
+// ---- ONE VERY LONG separable row (round 4) -----------------------------------------------------------------------------
+// A linear objective is stored as a row of the structure (up to n entries), a nonlinear one as the epigraph row (n + 1 entries:
+// src/nlpeval.jl:49-54).  With G lanes per row ONE lane group walked it: 3 125 dependent trips for 1e5 entries -- the 1.9 ms that
+// `ktn_sep_precompute` took on a 1e6-row instance were this one row, not the million short ones (profiles/r04_*), and every sweep
+// of a model with a nonlinear objective paid it too.  Rows beyond kLongEval entries carry the device-side row kind kRowSepLong:
+// every row kernel skips them (they test for KTN_ROW_SEP), k_emit takes their derivatives from the materialised Jacobian, and this
+// kernel evaluates them, one 1 024-thread workgroup per row (thread-strided partial sums, wavefront butterflies, the block's
+// wavefronts in order: a fixed summation order).
+constexpr int kLongEval = 8192;
+constexpr uint8_t kRowSepLong = 3;
+__global__ __launch_bounds__(1024) void k_sep_eval_long(NlpDev P, const int32_t* __restrict__ rows, const int64_t* __restrict__ slots,
+                                                        const double* __restrict__ x, double f_tol, int flags_on, SweepOut O) {
+    __shared__ double sh[16][3];
+    __shared__ int shn[16];
+    const int32_t r = rows[blockIdx.x];
+    const int64_t beg = P.rowptr[r], end = P.rowptr[r + 1];
+    double acc_g = 0.0, acc_dot = 0.0, mx = -__builtin_inf();
+    int nf = 0;
+    for (int64_t e = beg + threadIdx.x; e < end; e += 1024) {
+        const int ck = P.colk[e];
+        const double2 q = P.pp[e];
+        const double xv = x[ck & kColMask];
+        double val, der;
+        atom_eval((unsigned)ck >> kKindShift, q.x, q.y, xv, val, der);
+        acc_g += val; acc_dot += xv * der; mx = nanmax(mx, der); nf |= !isfinite(der);
+        O.jac[e] = der;
+    }
+    acc_g = group_sum<64>(acc_g); acc_dot = group_sum<64>(acc_dot); mx = group_nanmax<64>(mx); nf = group_or<64>(nf);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[wv][0] = acc_g; sh[wv][1] = acc_dot; sh[wv][2] = mx; shn[wv] = nf; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int k = 1; k < 16; ++k) { acc_g += sh[k][0]; acc_dot += sh[k][1]; mx = nanmax(mx, sh[k][2]); nf |= shn[k]; }
+    const double g = acc_g + P.rconst[r];
+    if (P.pad_zero[r]) mx = nanmax(mx, 0.0);
+    O.g[r] = g; O.bconst[r] = g - acc_dot; O.maxc[r] = mx; O.nonfin[r] = nf;
+    const int64_t slot = slots[blockIdx.x];
+    if (flags_on && slot >= 0) {
+        const double lb = P.lb[r], ub = P.ub[r];
+        const bool sat = (g >= lb - f_tol) && (g <= ub + f_tol);   // separators.jl:120 (NaN -> violated)
+        O.flag[slot] = sat ? 0 : 1;
+        O.cnt[slot] = sat ? 0 : (end - beg);
+        if (!sat) {
+            double v = fmax(g - ub, lb - g);
+            if (v != v) v = __builtin_inf();
+            atomicMax(reinterpret_cast<unsigned long long*>(O.maxviol), (unsigned long long)__double_as_longlong(v));
+            if (nf) atomicOr(O.any_nonfin, 1);
+        }
+    }
+}
+
 // ---- batch-blocked sweep for MANY SHORT rows (round 4; cfg4: 1e6 rows of 32 entries) ---------------
 // The row kernel above gathers x*[col] from L2 once per ENTRY: 3.2e7 eight-byte gathers, each its own L1 miss that drags a
 // 128-byte line -- 4 GB of L2->L1 traffic per sweep, which is what bounds it at 19 % of the HBM peak.  A short row cannot be
@@ -683,7 +734,7 @@ __global__ __launch_bounds__(kBlock) void k_gj_stats(NlpDev P, const int32_t* __
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= m_nl) return;
     const int32_t r = nl_rows[gid];
-    if (kind_filter >= 0 && P.row_kind[r] == KTN_ROW_SEP) return;     // tape rows and host-evaluated rows
+    if (kind_filter >= 0 && (P.row_kind[r] == KTN_ROW_SEP || P.row_kind[r] == 3)) return;     // tape rows and host-evaluated rows (3 = kRowSepLong: k_sep_eval_long's)
     const int64_t beg = P.rowptr[r], end = P.rowptr[r + 1];
     const double g = O.g[r];
     double b = g, mx = -__builtin_inf();

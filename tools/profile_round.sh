@@ -27,7 +27,7 @@ run_pmc spmv_hbm FETCH_SIZE $R/tools/spmv_bench.py 1000000 8
 run_pmc spmv_hbm WRITE_SIZE $R/tools/spmv_bench.py 1000000 8
 run_stats sweep_hbm $R/tools/sweep_bench.py cfg3_hbm 20
 run_pmc sweep_hbm FETCH_SIZE $R/tools/sweep_bench.py cfg3_hbm 8
-run_stats sweep_short $R/tools/sweep_viol.py cfg4 8          # the row sweep on 1e6 short rows (bench.py sweep_roofline_short_rows)
+run_stats sweep_short $R/tools/sweep_viol.py cfg4 8          # the sweep on 1e6 short rows (bench.py sweep_roofline_short_rows) and the materialising precompute!
 cd $R
 python3 bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
 python3 tools/spmv_bench.py 1000000 40 2>/dev/null | tail -1 > $OUT/spmv_hbm.json
