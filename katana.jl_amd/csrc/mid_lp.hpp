@@ -120,7 +120,11 @@ __global__ __launch_bounds__(256) void k_mid_init(MidLpIO P) {
     }
 }
 
-// pricing: most violated side, normalised by the side's norm.  Item i < m: row i (both sides); item m + j: variable j.
+// pricing: most violated side, normalised by the side's norm.  Rows: 8 lanes per row, coalesced entry loads, xor-butterfly (one
+// thread per row walked 16 - 32 entries in as many dependent round trips: a pivot took 36 us, with this 29); variables: one
+// thread each.  (Measured and NOT kept, round 4: the whole pivot in one 1 024-thread workgroup -- 35 us, pricing 2.7 MB through one
+// CU's L2 port; pricing + one fused single-workgroup launch for the rest -- 42 us with the rank-one update inside it (a 50-trip
+// dependent loop per thread), 26 - 29 us with the rank-one update as a third launch: no better than these five small launches.)
 __global__ __launch_bounds__(256) void k_mid_price(MidLpIO P) {
     __shared__ double sv[256];
     __shared__ int si[256];
@@ -128,11 +132,13 @@ __global__ __launch_bounds__(256) void k_mid_price(MidLpIO P) {
     double bestv = 0.0;
     int besti = 0x7fffffff;
     if (P.st->status == 0) {
-        const int64_t items = P.m + P.n;
-        for (int64_t it = (int64_t)blockIdx.x * 256 + t; it < items; it += (int64_t)gridDim.x * 256) {
-            if (it < P.m) {
-                double act = 0.0, n2 = 0.0;
-                for (int64_t e = P.rowptr[it]; e < P.rowptr[it + 1]; ++e) { const double a = P.val[e]; act += a * P.x[P.col[e]]; n2 += a * a; }
+        const int lane = t & 7;
+        const int64_t g0 = ((int64_t)blockIdx.x * 256 + t) >> 3, ng = ((int64_t)gridDim.x * 256) >> 3;
+        for (int64_t it = g0; it < P.m; it += ng) {
+            double act = 0.0, n2 = 0.0;
+            for (int64_t e = P.rowptr[it] + lane; e < P.rowptr[it + 1]; e += 8) { const double a = P.val[e]; act += a * P.x[P.col[e]]; n2 += a * a; }
+            act = group_sum<8>(act); n2 = group_sum<8>(n2);
+            if (lane == 0) {
                 const double nrm = fmax(sqrt(n2), 1e-300);
                 const double hi = P.hi[it], lo = P.lo[it];
                 const double vu = (hi == hi && hi < __builtin_inf()) ? (act - hi) / nrm : -1.0;
@@ -140,15 +146,15 @@ __global__ __launch_bounds__(256) void k_mid_price(MidLpIO P) {
                 const int k = (vl > vu) ? (int)(2 * it + 1) : (int)(2 * it);
                 const double v = fmax(vu, vl);
                 if (v > bestv || (v == bestv && v > 0.0 && k < besti)) { bestv = v; besti = k; }
-            } else {
-                const int j = (int)(it - P.m);
-                const double xj = P.x[j];
-                const double vu = (P.u[j] < kDenseBig) ? xj - P.u[j] : -1.0;
-                const double vl = (-P.l[j] < kDenseBig) ? P.l[j] - xj : -1.0;
-                const int k = -1 - (2 * j + ((vl > vu) ? 1 : 0));
-                const double v = fmax(vu, vl);
-                if (v > bestv || (v == bestv && v > 0.0 && k < besti)) { bestv = v; besti = k; }
             }
+        }
+        for (int64_t j = (int64_t)blockIdx.x * 256 + t; j < P.n; j += (int64_t)gridDim.x * 256) {
+            const double xj = P.x[j];
+            const double vu = (P.u[j] < kDenseBig) ? xj - P.u[j] : -1.0;
+            const double vl = (-P.l[j] < kDenseBig) ? P.l[j] - xj : -1.0;
+            const int k = -1 - (2 * (int)j + ((vl > vu) ? 1 : 0));
+            const double v = fmax(vu, vl);
+            if (v > bestv || (v == bestv && v > 0.0 && k < besti)) { bestv = v; besti = k; }
         }
     }
     sv[t] = bestv; si[t] = besti;
