@@ -1289,6 +1289,7 @@ void Engine::loadproblem(int64_t num_var, int64_t num_constr, const double* l_va
             if (slot_of[(size_t)i] >= 0) { lnr.push_back((int32_t)i); lns.push_back(slot_of[(size_t)i]); }
         }
         n_longev = (int64_t)lr.size(); n_longev_nl = (int64_t)lnr.size();
+        stats["sep_long_rows"] = (double)n_longev;
         if (n_longev > 0) {
             d_rowkind.upload(dk, stream);
             d_longev_rows.upload(lr, stream); d_longev_slots.upload(ls, stream);

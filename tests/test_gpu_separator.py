@@ -302,3 +302,72 @@ def test_full_size_hbm_resident_sweep_blocked_equals_row_kernel(monkeypatch):
     assert abs(a[1] - b[1]) <= 1e-11 * max(1.0, abs(a[1]))
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     assert np.allclose(a[5], b[5], rtol=1e-11, atol=1e-11)
+
+
+def test_very_long_rows_go_through_the_long_row_kernel():
+    """Round 4: a separable row beyond 8 192 entries (a linear objective stored as a row, the dense epigraph row of a nonlinear
+    objective, a constraint over most variables) is evaluated by k_sep_eval_long -- one workgroup per row -- instead of one lane
+    group walking it; every row kernel skips it, k_emit takes its derivatives from the materialised Jacobian.  Same tolerances
+    against the oracle as the short rows: precompute!, gencut, and the cuts a sweep appends."""
+    from oracle.evaluators import _atoms
+    inst = ktn.instances.make_instance(n=12000, m_nl=4, k=9000, family="explog", seed=5, m_lin=50)
+    rng = np.random.default_rng(2)
+    x = rng.uniform(inst.l_var, inst.u_var)
+    m = hip_load_instance(ktn, inst, purge_age=0, cut_cap_factor=0.0)
+    assert m.stat("sep_long_rows") >= 4                               # the four NL rows (and the objective row, 1e4 entries)
+    sep = ktn.KatanaHipSeparator(m)
+    sep.initialize()
+    sep.precompute(x)
+    osep = _oracle_sep(inst, x)
+    jac_o = osep.jac[osep.csr_ind]
+    assert np.all(np.abs(sep.jac - jac_o) <= ULP4 * np.abs(jac_o) + 1e-300)
+    val, _ = _atoms(inst.kind.astype(np.int64), inst.p0, inst.p1, x[inst.col])
+    rows = np.repeat(np.arange(inst.num_constr), np.diff(inst.rowptr))
+    mag = np.bincount(rows, weights=np.abs(val), minlength=inst.num_constr) + np.abs(inst.rconst)
+    assert np.all(np.abs(sep.g - osep.g) <= 1e-13 * (mag + 1.0))
+    nl = np.arange(inst.m_lin, inst.num_constr)
+    viol_o = [i for i in nl if not osep.isconstrsat(i, inst.l_constr[i], inst.u_constr[i], 1e-6)]
+    assert len(viol_o) >= 1
+    m0 = m.lp_num_rows()
+    nv, mv = sep.sweep(1e-6)
+    assert nv == len(viol_o)
+    rowptr, col, valr, lo, hi = m.lp_rows()
+    for kcut, i in enumerate(viol_o):
+        cut = linear_oa_cut(osep, x, None, i)
+        round_coefs(cut, 1e9)
+        beg, end = rowptr[m0 + kcut], rowptr[m0 + kcut + 1]
+        assert list(col[beg:end]) == list(cut.vars)
+        assert np.all(np.abs(valr[beg:end] - cut.coeffs) <= ULP4 * np.abs(cut.coeffs) + 1e-300)
+        dotmag = np.sum(np.abs(x[cut.vars] * np.asarray(cut.coeffs))) + mag[i] + 1.0
+        assert abs(hi[m0 + kcut] - (inst.u_constr[i] - cut.constant)) <= 1e-13 * dotmag
+
+
+def test_batch_blocked_sweep_equals_the_row_kernel_and_is_bitwise_reproducible(monkeypatch):
+    """Round 4: k_sep_sweep_batch (2 048 NL slots per workgroup, x* staged through LDS in 64 KB blocks, kind-uniform entry-parallel
+    chunks, deterministic run sums) against the row kernel on the same instance and point, both in one process (the switch is read
+    per handle): the same violated rows and cuts (structure exactly, values to the sum tolerance), and two sweeps of the batched
+    kernel give the same bits.  (By default the kernel is used from 7.9e5 NL rows on -- the full-size cfg4 test runs through it.)"""
+    inst = ktn.instances.make_instance(n=20000, m_nl=30000, k=32, family="explog", seed=8, m_lin=200)
+    x = np.clip(inst.xhat + 0.3, inst.l_var, inst.u_var)
+    out = {}
+    for label, env in (("row", "0"), ("batch", "1")):
+        monkeypatch.setenv("KTN_SWEEP_BATCHED", env)
+        m = hip_load_instance(ktn, inst, purge_age=0, cut_cap_factor=0.0)
+        assert m.stat("sweep_batched") == (1.0 if label == "batch" else 0.0)
+        sep = ktn.KatanaHipSeparator(m); sep.initialize()
+        sep.precompute(x)
+        res = []
+        for rep in range(2):
+            nv, mv = sep.sweep(1e-6)
+            res.append((nv, mv) + tuple(a.copy() for a in m.lp_rows()))
+            m.reset(); sep.precompute(x)
+        out[label] = res
+    monkeypatch.delenv("KTN_SWEEP_BATCHED")
+    (nv_r, mv_r, rp_r, col_r, val_r, lo_r, hi_r), (nv_b, mv_b, rp_b, col_b, val_b, lo_b, hi_b) = out["row"][0], out["batch"][0]
+    assert nv_r == nv_b > 100 and abs(mv_r - mv_b) <= 1e-12 * (1.0 + abs(mv_r))
+    assert np.array_equal(rp_r, rp_b) and np.array_equal(col_r, col_b)
+    assert np.array_equal(val_r, val_b)                               # the coefficients come from k_emit either way
+    fin = np.isfinite(hi_r)
+    assert np.array_equal(fin, np.isfinite(hi_b)) and np.all(np.abs(hi_r[fin] - hi_b[fin]) <= 1e-12 * (1.0 + np.abs(hi_r[fin])))
+    again = out["batch"][1]
+    assert again[0] == nv_b and again[1] == mv_b and all(np.array_equal(p, q) for p, q in zip(again[2:], out["batch"][0][2:]))
