@@ -198,7 +198,7 @@ def test_two_rank_sharded_solve_refines_by_the_objective_certificate():
     """cfg3 seed 6 meets the stop rule 1.5e-6 (relative) away from the optimum; the engine's own loop then keeps cutting below
     f_tol until the objective certificate -- sum over the NL rows of multiplier mass x residual -- is within half the
     reference's objective tolerance.  With the NL rows split over two ranks every rank contributes its block's share
-    (ktn_objective_certificate) and the host loop takes the same decision: one refinement, the objective within 1e-6 / 1e-6 of
+    (ktn_objective_certificate, summed through the exchange callback) and every rank's engine takes the same decision: one refinement, the objective within 1e-6 / 1e-6 of
     the planted one, the single-GPU trajectory bit for bit."""
     import katana_jl_amd as ktn
     from helpers import assert_planted_objective, hip_load_instance
