@@ -122,6 +122,102 @@ def test_pack_unpack_roundtrip_with_empty_and_ragged_blocks():
         assert len(got) == 6 and np.array_equal(got[5], ids) and np.array_equal(got[1], col)
 
 
+class _RecordingLp:
+    """stands in for the engine handle behind ShardedKatanaModel._exchange: rows [m0, M) of "its LP" are the block given at
+    construction; truncate / append are recorded"""
+    def __init__(self, m0, block, slots):
+        self.m0, self.block, self.slots = m0, block, slots
+        self.rows = m0 + len(block[3])
+        self.appended = []
+
+    def lp_rows_from(self, first):
+        assert first == self.m0
+        return self.block
+
+    def last_sweep_slots(self):
+        return self.slots
+
+    def lp_truncate(self, first):
+        assert first == self.m0
+        self.rows = first
+
+    def lp_append_rows(self, rp, col, val, lo, hi, ids):
+        self.appended.append((np.array(rp), np.array(col), np.array(val), np.array(lo), np.array(hi), np.array(ids)))
+        self.rows += len(lo)
+
+
+def _worker_exchange_callback(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from katana_jl_amd.distributed import ShardedKatanaModel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    nrows = 3 + 2 * rank                                             # ragged: 3 rows on rank 0, 5 on rank 1
+    lens = rng.integers(1, 6, nrows)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    block = (rp, rng.integers(0, 50, int(rp[-1])).astype(np.int32), rng.normal(size=int(rp[-1])),
+             np.full(nrows, -np.inf), rng.normal(size=nrows))
+    shard_lo = 40 * rank
+    obj = ShardedKatanaModel.__new__(ShardedKatanaModel)             # the callback alone: no engine, no GPU
+    obj.rank, obj.world, obj.dist, obj.exchange_device, obj.shard_lo = rank, world, dist, "cpu", shard_lo
+    obj.exchanged_rows = 0
+    res = {}
+    # round 1: both ranks have rows; scalars = (unused, max violation, flag, extra0, extra1)
+    obj.m = _RecordingLp(17, block, np.arange(nrows, dtype=np.int64))
+    sc = [0.0, 0.25 * (rank + 1), float(rank), -1.0 - rank, 7.0]
+    rc = obj._exchange(None, 0, 17, sc, 5)
+    res["r1"] = (rc, list(sc), obj.m.rows, obj.m.appended, block)
+    # round 2: rank 1's LP failed (flag 2): nothing is appended anywhere, every rank sees the flag
+    obj.m = _RecordingLp(17, block, np.arange(nrows, dtype=np.int64))
+    sc = [0.0, 0.5, 2.0 if rank == 1 else 0.0, 0.0, 0.0]
+    rc = obj._exchange(None, 0, 17, sc, 5)
+    res["r2"] = (rc, list(sc), obj.m.rows, len(obj.m.appended))
+    # what = 1: the sum over the ranks, in place
+    sc = [1.0 + rank, -2.0 * (rank + 1), 0.5]
+    rc = obj._exchange(None, 1, 0, sc, 3)
+    res["sum"] = (rc, list(sc))
+    res["exchanged_rows"] = obj.exchanged_rows
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_engine_side_exchange_callback_protocol_over_gloo():
+    """what Engine::step sees through ktn_set_cut_exchange (include/katana_hip.h): totals, maxima, sums and -- the point of the
+    exchange -- the same rows in the same order in every rank's LP, ids shifted to the global NL-row numbering"""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_exchange_callback, args=(world, _free_port(), out), nprocs=world, join=True)
+    blocks = [out[r]["r1"][4] for r in range(world)]
+    for rank in range(world):
+        rc, sc, rows, appended, _ = out[rank]["r1"]
+        assert rc == 0
+        assert sc[0] == 8.0 and sc[1] == 0.5 and sc[2] == 1.0 and sc[3] == -1.0 and sc[4] == 7.0
+        assert rows == 17 + 8 and len(appended) == world
+        for r in range(world):
+            for got, want in zip(appended[r][:5], blocks[r]):
+                assert np.array_equal(got, want)
+            assert np.array_equal(appended[r][5], 40 * r + np.arange(3 + 2 * r))
+        rc, sc, rows, napp = out[rank]["r2"]
+        assert rc == 0 and sc[0] == 0.0 and sc[2] == 2.0 and rows == 17 and napp == 0
+        rc, sc = out[rank]["sum"]
+        assert rc == 0 and sc == [3.0, -6.0, 1.0]
+        assert out[rank]["exchanged_rows"] == 8
+
+
+def test_exchange_callback_reports_failure_instead_of_raising_across_the_abi(capsys):
+    from katana_jl_amd.distributed import ShardedKatanaModel
+    obj = ShardedKatanaModel.__new__(ShardedKatanaModel)
+    obj.rank, obj.world, obj.dist, obj.exchange_device, obj.shard_lo, obj.exchanged_rows = 0, 1, None, "cpu", 0, 0
+
+    class Broken:
+        def lp_rows_from(self, first):
+            raise RuntimeError("device lost")
+    obj.m = Broken()
+    assert obj._exchange(None, 0, 3, [0.0, 1.0, 0.0, 0.0, 0.0], 5) == 1
+    assert "cut-exchange callback failed" in capsys.readouterr().err
+
+
 def _worker_gpu(rank, world, port, out, inst_kw=None, solver_kw=None, exchange_device=None):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
