@@ -119,7 +119,7 @@ __device__ __forceinline__ void ecp_spmv(int count, const int32_t* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
+static __global__ __launch_bounds__(kEcpThreads) void k_ecp_blocks(EcpBatch B) {
     extern __shared__ double sm[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t c0 = B.blk_col[b];

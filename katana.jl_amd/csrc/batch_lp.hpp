@@ -99,7 +99,7 @@ __device__ __forceinline__ void blk_dots(int o0, int stride, int count, int lane
     }
 }
 
-__global__ __launch_bounds__(kBlkThreads) void k_pdhg_blocks(BlkLp P) {
+static __global__ __launch_bounds__(kBlkThreads) void k_pdhg_blocks(BlkLp P) {
     extern __shared__ double sm[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t c0 = P.blk_col[b];
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kBlkThreads) void k_pdhg_blocks(BlkLp P) {
 }
 
 // row -> block (binary search of the row's first column in blk_col); rows without entries go to block 0
-__global__ __launch_bounds__(kBlock) void k_row_block(int64_t m, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+static __global__ __launch_bounds__(kBlock) void k_row_block(int64_t m, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                       const int64_t* __restrict__ blk_col, int nblk, uint64_t* __restrict__ keys,
                                                       uint32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void k_row_block(int64_t m, const int64_t* 
     vals[i] = (uint32_t)i;
 }
 // sorted (block, row) pairs -> block row pointers, row list, local position of every row
-__global__ __launch_bounds__(kBlock) void k_block_rows(int64_t m, const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+static __global__ __launch_bounds__(kBlock) void k_block_rows(int64_t m, const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
                                                        int nblk, int32_t* __restrict__ blk_rowptr, int32_t* __restrict__ blk_rows,
                                                        int32_t* __restrict__ row_loc) {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -393,13 +393,13 @@ __global__ __launch_bounds__(kBlock) void k_block_rows(int64_t m, const uint64_t
     for (int bb = prevb + 1; bb <= b; ++bb) blk_rowptr[bb] = (int32_t)p;      // first position of every block up to b
     if (p == m - 1) for (int bb = b + 1; bb <= nblk; ++bb) blk_rowptr[bb] = (int32_t)m;
 }
-__global__ __launch_bounds__(kBlock) void k_row_local(int64_t m, const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+static __global__ __launch_bounds__(kBlock) void k_row_local(int64_t m, const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
                                                       const int32_t* __restrict__ blk_rowptr, int32_t* __restrict__ row_loc) {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= m) return;
     row_loc[svals[p]] = (int32_t)(p - blk_rowptr[(int)skeys[p]]);
 }
-__global__ __launch_bounds__(kBlock) void k_localize_rows(int64_t nnz, const int32_t* __restrict__ crow, const int32_t* __restrict__ row_loc,
+static __global__ __launch_bounds__(kBlock) void k_localize_rows(int64_t nnz, const int32_t* __restrict__ crow, const int32_t* __restrict__ row_loc,
                                                           int32_t* __restrict__ crowl) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e < nnz) crowl[e] = row_loc[crow[e]];

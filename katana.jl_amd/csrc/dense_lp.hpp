@@ -88,7 +88,7 @@ __device__ __forceinline__ double dense_side_dot(const DenseLpIO& P, int64_t k, 
     return ((-1 - k) & 1) ? -x[j] : x[j];
 }
 
-__global__ __launch_bounds__(256) void k_dense_lp(DenseLpIO P) {
+static __global__ __launch_bounds__(256) void k_dense_lp(DenseLpIO P) {
     constexpr int N = kDenseMaxN;
     __shared__ double Aug[N][2 * N];     // [B | I] -> [I | B^-1]
     __shared__ double hW[N], xs[N], lam[N], uvec[N], gq[N], cs[N];

@@ -19,15 +19,12 @@
 #include <type_traits>
 
 #include "../../include/katana_hip.h"
+#include "types.hpp"
 
 namespace ktn {
 
-constexpr int kBlock = 256;
-constexpr int kRedBlocks = 256;   // blocks of the two-stage deterministic reductions
-constexpr int kChkQ = 16;         // quantities per check partial
 constexpr int kKindShift = 29;    // packed (col | kind << 29): columns < 2^29
 constexpr int kColMask = (1 << kKindShift) - 1;
-constexpr int kBlkCols = 8192;    // columns of x* staged in LDS per workgroup of the column-blocked sweep (64 KB)
 
 // ---------------------------------------------------------------- small helpers ----
 template <int G>
@@ -88,7 +85,7 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 // Six scalars a sweep / a purge hands back to the host -- the last elements of two (flag, exclusive scan) pairs, the
 // largest violation and two int flags -- written by ONE thread into pinned, device-mapped host memory instead of six
 // device-to-host copies (a copy kernel of ~4.5 us each).  Counts are exact in a double below 2^53.
-__global__ void k_host_tail(double* __restrict__ out, const int64_t* __restrict__ a, const int64_t* __restrict__ b,
+static __global__ void k_host_tail(double* __restrict__ out, const int64_t* __restrict__ a, const int64_t* __restrict__ b,
                             const int64_t* __restrict__ c, const int64_t* __restrict__ d, const double* __restrict__ mv,
                             const int32_t* __restrict__ f0, const int32_t* __restrict__ f1) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -322,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void k_sep_sweep(NlpDev P, const int32_t* _
 // wavefronts in order: a fixed summation order).
 constexpr int kLongEval = 8192;
 constexpr uint8_t kRowSepLong = 3;
-__global__ __launch_bounds__(1024) void k_sep_eval_long(NlpDev P, const int32_t* __restrict__ rows, const int64_t* __restrict__ slots,
+static __global__ __launch_bounds__(1024) void k_sep_eval_long(NlpDev P, const int32_t* __restrict__ rows, const int64_t* __restrict__ slots,
                                                         const double* __restrict__ x, double f_tol, int flags_on, SweepOut O) {
     __shared__ double sh[16][3];
     __shared__ int shn[16];
@@ -389,7 +386,7 @@ struct SbView {
     const int64_t* seg;      // [(batches * nb + 1) * 4]: first entry of (batch, block, kind); the last slot closes the list
     int nb;                  // column blocks
 };
-__global__ __launch_bounds__(kSbThreads) void k_sep_sweep_batch(SbView V, NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
+static __global__ __launch_bounds__(kSbThreads) void k_sep_sweep_batch(SbView V, NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
                                                                 const double* __restrict__ x, int64_t n_x, double f_tol, SweepOut O) {
     extern __shared__ double sb_sm[];
     double* xs = sb_sm;
@@ -602,7 +599,7 @@ __global__ __launch_bounds__(BS) void k_sep_eval_blk(const int32_t* __restrict__
 // 32-byte record (no nl_rows -> row_kind -> bounds pointer chase: the kernel is 10 000 threads of pure latency).
 struct SepSlot { double rconst, lb, ub; int32_t row; int32_t len_pad; };   // len_pad = row length << 1 | pad_zero; row < 0: not separable
 
-__global__ __launch_bounds__(kBlock) void k_sep_combine(const SepSlot* __restrict__ slots, int64_t m_nl, int NB,
+static __global__ __launch_bounds__(kBlock) void k_sep_combine(const SepSlot* __restrict__ slots, int64_t m_nl, int NB,
                                                         const SepPartial* __restrict__ part, double f_tol, SweepOut O) {
     const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (s >= m_nl) return;
@@ -637,7 +634,7 @@ __global__ __launch_bounds__(kBlock) void k_sep_combine(const SepSlot* __restric
 // ---- deepest-cut selection (cut_cap): depth keys of the violated rows, then re-flagging against the threshold ----
 // key = bit pattern of the violation depth max(g - ub, lb - g) (non-negative doubles order like unsigned integers;
 // NaN counts as +inf), 0 for satisfied rows.
-__global__ __launch_bounds__(kBlock) void k_depth_keys(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
+static __global__ __launch_bounds__(kBlock) void k_depth_keys(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
                                                        const double* __restrict__ g, const int64_t* __restrict__ flag,
                                                        uint64_t* __restrict__ keys) {
     const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -651,7 +648,7 @@ __global__ __launch_bounds__(kBlock) void k_depth_keys(NlpDev P, const int32_t* 
     }
     keys[s] = k;
 }
-__global__ __launch_bounds__(kBlock) void k_depth_reflag(int64_t m_nl, const uint64_t* __restrict__ keys,
+static __global__ __launch_bounds__(kBlock) void k_depth_reflag(int64_t m_nl, const uint64_t* __restrict__ keys,
                                                          const uint64_t* __restrict__ sorted_desc, int64_t keep,
                                                          int64_t* __restrict__ flag, int64_t* __restrict__ cnt) {
     const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -663,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void k_depth_reflag(int64_t m_nl, const uin
 // precompute! for tape rows: one thread per row, forward sweep then reverse sweep over
 // the row's expression DAG.  Derivative conventions follow the oracle (oracle/sexpr.py):
 // log' = 1/v, sqrt' = 0.5/sqrt(v), pow: 2 -> 2v, 1 -> 1, else p v^(p-1).
-__global__ __launch_bounds__(kBlock) void k_tape_eval(NlpDev P, const int32_t* __restrict__ tape_rows, int64_t n_tape,
+static __global__ __launch_bounds__(kBlock) void k_tape_eval(NlpDev P, const int32_t* __restrict__ tape_rows, int64_t n_tape,
                                                       const double* __restrict__ x, SweepOut O) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= n_tape) return;
@@ -728,7 +725,7 @@ __global__ __launch_bounds__(kBlock) void k_tape_eval(NlpDev P, const int32_t* _
 // linear_oa_cut constant / round_coefs max / finite check / isconstrsat from a
 // materialised Jacobian row (tape rows; also the host-evaluator fallback of section 8b).
 // One thread per row, entries in storage order == the reference's left-to-right order.
-__global__ __launch_bounds__(kBlock) void k_gj_stats(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
+static __global__ __launch_bounds__(kBlock) void k_gj_stats(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
                                                      const double* __restrict__ x, double f_tol, int kind_filter,
                                                      SweepOut O) {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -760,7 +757,7 @@ __global__ __launch_bounds__(kBlock) void k_gj_stats(NlpDev P, const int32_t* __
 }
 
 // KTN_ROW_HOST rows: values and Jacobian entries computed by the caller's evaluator, staged in (gh, jh)
-__global__ __launch_bounds__(kBlock) void k_host_scatter(NlpDev P, const int32_t* __restrict__ host_rows, int64_t n_host,
+static __global__ __launch_bounds__(kBlock) void k_host_scatter(NlpDev P, const int32_t* __restrict__ host_rows, int64_t n_host,
                                                          const double* __restrict__ gh, const double* __restrict__ jh, SweepOut O) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= n_host) return;
@@ -770,7 +767,7 @@ __global__ __launch_bounds__(kBlock) void k_host_scatter(NlpDev P, const int32_t
 }
 
 // loadproblem!: the packed row programs (col | kind << 29, (p0, p1)) from the caller's separate arrays
-__global__ __launch_bounds__(kBlock) void k_pack_atoms(int64_t nnz, const int32_t* __restrict__ col, const uint8_t* __restrict__ kind,
+static __global__ __launch_bounds__(kBlock) void k_pack_atoms(int64_t nnz, const int32_t* __restrict__ col, const uint8_t* __restrict__ kind,
                                                        const double* __restrict__ p0, const double* __restrict__ p1,
                                                        int32_t* __restrict__ colk, double2* __restrict__ pp) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -781,7 +778,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_atoms(int64_t nnz, const int32_
 // loadproblem!: the linear rows of the LP from the tangent at the origin (src/model.jl:110-122): row r of the LP is
 // constraint lin_rows[r]; coefficients = its Jacobian entries at 0, bounds [l - b, u - b] with b = g(0) - sum 0 * J.
 // lp_rowptr is already in place (the row lengths are structural).
-__global__ __launch_bounds__(kBlock) void k_lin_rows(int64_t nlin, const int32_t* __restrict__ lin_rows, const int64_t* __restrict__ rowptr,
+static __global__ __launch_bounds__(kBlock) void k_lin_rows(int64_t nlin, const int32_t* __restrict__ lin_rows, const int64_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ col, const double* __restrict__ jac,
                                                      const double* __restrict__ g, const double* __restrict__ lb, const double* __restrict__ ub,
                                                      const int64_t* __restrict__ lp_rowptr, int32_t* __restrict__ lp_col,
@@ -814,7 +811,7 @@ struct LpRows {
 // _addcut bookkeeping after the scans: row bounds (lb - b, ub - b), new rowptr entries,
 // violated-row list, and the dual warm start (new cut inherits the dual of the previous
 // cut of the same NL row).
-__global__ __launch_bounds__(kBlock) void k_compact(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
+static __global__ __launch_bounds__(kBlock) void k_compact(NlpDev P, const int32_t* __restrict__ nl_rows, int64_t m_nl,
                                                     const int64_t* __restrict__ flag, const int64_t* __restrict__ rank,
                                                     const int64_t* __restrict__ cnt_scan, const double* __restrict__ bconst,
                                                     int64_t base_row, int64_t base_nnz, LpRows L,
@@ -842,7 +839,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(NlpDev P, const int32_t* __r
 
 // Rows appended from the host (multi-GPU exchange) join the per-NL-row cut lists through their GLOBAL NL-row id:
 // the same bookkeeping k_compact does for the rows of a local sweep (dual inheritance, list threading).
-__global__ __launch_bounds__(kBlock) void k_append_link(int64_t nrows, int64_t base_row, const int64_t* __restrict__ nl_id,
+static __global__ __launch_bounds__(kBlock) void k_append_link(int64_t nrows, int64_t base_row, const int64_t* __restrict__ nl_id,
                                                        int64_t nl_total, int64_t* __restrict__ glast,
                                                        int64_t* __restrict__ cut_prev, double* __restrict__ y, int inherit) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -868,7 +865,7 @@ __global__ __launch_bounds__(kBlock) void k_append_link(int64_t nrows, int64_t b
 // cut (unscaled duals, so A'y changes only by mass * (difference of two nearly equal rows)).  Cuts
 // that are tight keep their multipliers, so a vertex formed by several cuts of one row is untouched.
 // One thread per NL slot walks that slot's list; sequential => deterministic.
-__global__ __launch_bounds__(kBlock) void k_consolidate(int64_t m_nl, const int64_t* __restrict__ last_cut,
+static __global__ __launch_bounds__(kBlock) void k_consolidate(int64_t m_nl, const int64_t* __restrict__ last_cut,
                                                         const int64_t* __restrict__ cut_prev, const double* __restrict__ ax,
                                                         const double* __restrict__ lo, const double* __restrict__ hi,
                                                         const double* __restrict__ dr, double thresh,
@@ -994,7 +991,7 @@ __global__ __launch_bounds__(kBlock) void k_purge_copy(int64_t m, const int64_t*
     }
 }
 // re-thread the per-NL-row cut lists (k_consolidate) through the kept rows
-__global__ __launch_bounds__(kBlock) void k_purge_relink(int64_t m_nl, int64_t* __restrict__ last_cut,
+static __global__ __launch_bounds__(kBlock) void k_purge_relink(int64_t m_nl, int64_t* __restrict__ last_cut,
                                                          const int64_t* __restrict__ prev_old, const int64_t* __restrict__ keep,
                                                          const int64_t* __restrict__ newidx, int64_t* __restrict__ prev_new) {
     const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1161,7 +1158,7 @@ __global__ __launch_bounds__(1024) void k_pdhg_x_long(const int32_t* __restrict_
 struct __attribute__((aligned(32))) ColRec { double c, l, u, x0; };
 struct __attribute__((aligned(32))) RowRec { double lo, hi, y0; int32_t beg, len; };
 
-__global__ __launch_bounds__(kBlock) void k_pack_cols(int64_t n, const int64_t* __restrict__ ptr, const double* __restrict__ c,
+static __global__ __launch_bounds__(kBlock) void k_pack_cols(int64_t n, const int64_t* __restrict__ ptr, const double* __restrict__ c,
                                                       const double* __restrict__ l, const double* __restrict__ u,
                                                       const double* __restrict__ x, double* __restrict__ x0,
                                                       ColRec* __restrict__ rec, int2* __restrict__ bl) {
@@ -1173,7 +1170,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_cols(int64_t n, const int64_t* 
     rec[j] = r;
     bl[j] = make_int2((int)ptr[j], (int)(ptr[j + 1] - ptr[j]));
 }
-__global__ __launch_bounds__(kBlock) void k_pack_rows(int64_t m, const int64_t* __restrict__ ptr, const double* __restrict__ lo,
+static __global__ __launch_bounds__(kBlock) void k_pack_rows(int64_t m, const int64_t* __restrict__ ptr, const double* __restrict__ lo,
                                                       const double* __restrict__ hi, const double* __restrict__ y,
                                                       double* __restrict__ y0, RowRec* __restrict__ rec) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1422,7 +1419,7 @@ __global__ __launch_bounds__(kLongBlock) void k_pdhg_y_long(const int32_t* __res
         }
     }
 }
-__global__ __launch_bounds__(kBlock) void k_find_long(int64_t m, const int64_t* __restrict__ rowptr, int64_t thresh,
+static __global__ __launch_bounds__(kBlock) void k_find_long(int64_t m, const int64_t* __restrict__ rowptr, int64_t thresh,
                                                       int32_t* __restrict__ list, int32_t* __restrict__ count) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
@@ -1430,7 +1427,7 @@ __global__ __launch_bounds__(kBlock) void k_find_long(int64_t m, const int64_t* 
 }
 
 // the same for the columns of the mirror, with the longest length reported too (count[0]: long ones, count[1]: max length)
-__global__ __launch_bounds__(kBlock) void k_find_long_max(int64_t n, const int64_t* __restrict__ ptr, int64_t thresh,
+static __global__ __launch_bounds__(kBlock) void k_find_long_max(int64_t n, const int64_t* __restrict__ ptr, int64_t thresh,
                                                           int32_t* __restrict__ list, int32_t* __restrict__ count) {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     int len = 0;
@@ -1448,7 +1445,7 @@ __global__ __launch_bounds__(kBlock) void k_find_long_max(int64_t n, const int64
 
 // Restart: z <- T(z), anchor z0 <- T(z), primal and dual part in one launch (instead of four device-to-device copies);
 // the packed records of the plain steps carry x0 / y0 too.
-__global__ __launch_bounds__(kBlock) void k_restart_set(int64_t n, int64_t m, const double* __restrict__ xt, double* __restrict__ x,
+static __global__ __launch_bounds__(kBlock) void k_restart_set(int64_t n, int64_t m, const double* __restrict__ xt, double* __restrict__ x,
                                                        double* __restrict__ x0, const double* __restrict__ yt,
                                                        double* __restrict__ y, double* __restrict__ y0,
                                                        ColRec* __restrict__ crec, RowRec* __restrict__ rrec) {
@@ -1458,7 +1455,7 @@ __global__ __launch_bounds__(kBlock) void k_restart_set(int64_t n, int64_t m, co
 }
 // Halpern update of the primal and the dual part in one launch (after a check iteration that neither terminated nor
 // restarted); also refreshes xbar = 2 xt - x_old for nobody: the next x-step recomputes it
-__global__ __launch_bounds__(kBlock) void k_halpern2(int64_t n, int64_t m, double* __restrict__ x, const double* __restrict__ xt,
+static __global__ __launch_bounds__(kBlock) void k_halpern2(int64_t n, int64_t m, double* __restrict__ x, const double* __restrict__ xt,
                                                     const double* __restrict__ x0, double* __restrict__ y,
                                                     const double* __restrict__ yt, const double* __restrict__ y0, double w, double rho) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1469,7 +1466,7 @@ __global__ __launch_bounds__(kBlock) void k_halpern2(int64_t n, int64_t m, doubl
 // second stage of the deterministic reductions: one block of kRedBlocks threads per (side, quantity) -- blockIdx.x =
 // side * kChkQ + q, side 0: rows, 1: columns -- thread b owns the partial blocks b, b + kRedBlocks, ... in that order,
 // then a fixed-shape butterfly + LDS tree -> run-to-run identical sums.
-__global__ __launch_bounds__(kRedBlocks) void k_chk_final(const double* __restrict__ prow, int nrow, const double* __restrict__ pcol,
+static __global__ __launch_bounds__(kRedBlocks) void k_chk_final(const double* __restrict__ prow, int nrow, const double* __restrict__ pcol,
                                                           int ncol, double* __restrict__ out) {
     __shared__ double sh[kRedBlocks / 64];
     const int side = blockIdx.x / kChkQ, q = blockIdx.x - side * kChkQ;
@@ -1549,7 +1546,7 @@ __global__ __launch_bounds__(kBlock) void k_x_prox(int64_t n, const double* __re
     else xt[j] = xtv;
 }
 // column side of the check from the all-reduced A'yt (same sums as k_chk_cols; identical on every rank)
-__global__ __launch_bounds__(kBlock) void k_chk_cols_vec(int64_t n, const double* __restrict__ atyv, const double* __restrict__ x,
+static __global__ __launch_bounds__(kBlock) void k_chk_cols_vec(int64_t n, const double* __restrict__ atyv, const double* __restrict__ x,
                                                          const double* __restrict__ xt, const double* __restrict__ x0,
                                                          const double* __restrict__ c, const double* __restrict__ l,
                                                          const double* __restrict__ u, const double* __restrict__ dc,
@@ -1589,15 +1586,11 @@ __global__ __launch_bounds__(kBlock) void k_chk_cols_vec(int64_t n, const double
 //   * two slots alternate: a rank overwrites slot s at epoch e + 2 only after passing the barrier of epoch e + 1, which
 //     every peer enters after its reads of epoch e (stream order);
 //   * every spin is bounded (wall clock); a timeout is reported through *err (host-mapped) and turns into an error status.
-constexpr int kIpcMaxRanks = 8;
-struct IpcPeers {
-    double* data[kIpcMaxRanks];                    // rank r's exposed buffer: two slots of `cap` doubles
-    unsigned long long* flags[kIpcMaxRanks];       // rank r's flag words, one per source rank
-};
+// (kIpcMaxRanks, IpcPeers: types.hpp)
 __device__ __forceinline__ double ipc_load(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load((unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }
-__global__ __launch_bounds__(64) void k_ipc_barrier(IpcPeers P, int rank, int world, unsigned long long epoch, long long timeout_ticks,
+static __global__ __launch_bounds__(64) void k_ipc_barrier(IpcPeers P, int rank, int world, unsigned long long epoch, long long timeout_ticks,
                                                     int* __restrict__ err) {
     // A failure is STICKY and FAST: once *err is set (a peer did not arrive in time, or a peer said it failed) every later
     // barrier of this rank returns at once instead of spinning the full timeout again -- the host only looks at *err at the next
@@ -1650,7 +1643,7 @@ __global__ __launch_bounds__(kBlock) void k_x_prox_ipc(int64_t n, IpcPeers P, in
     if (UPDATE) { xbar[j] = 2.0 * xtv - xv; x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0[j]; }
     else xt[j] = xtv;
 }
-__global__ __launch_bounds__(kBlock) void k_probe_fill(int64_t n, double* __restrict__ v, double base) {
+static __global__ __launch_bounds__(kBlock) void k_probe_fill(int64_t n, double* __restrict__ v, double base) {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j < n) v[j] = base + 1e-3 * (double)(j % 1000);
 }
@@ -1671,13 +1664,7 @@ constexpr int kTilePer = 4;                              // outputs per thread
 constexpr int kTileOut = kTileThreads * kTilePer;        // outputs per tile
 constexpr int kTileIn = 8192;
 
-struct TiledMat {
-    const int64_t* segstart;   // [tiles * nb_in + 1] first entry of (tile, block)
-    const uint16_t* bptr;      // [tiles * nb_in * (kTileOut + 1)] entry offsets of the tile's outputs inside (tile, block)
-    const uint16_t* idx;       // local input index
-    const double* val;         // scaled values
-    int nb_in;                 // input blocks
-};
+// (TiledMat: types.hpp)
 
 // Per input block the workgroup (a) stages the block of the input vector in LDS, (b) multiplies the segment's entries
 // with their LDS-gathered inputs ENTRY-parallel -- thread t takes entries t, t + 1024, ...: perfectly coalesced, eight
@@ -1714,7 +1701,7 @@ struct TileCursor {
 // in sub-chunks of kTileChunk entries that never straddle a unit.  A ring of kTileRing register slots keeps the next
 // sub-chunks' loads in flight (issued right after a slot's products are written), so the ~2 us HBM latency is covered by
 // four sub-steps of work instead of stalling every one of them.
-__global__ __launch_bounds__(kTileThreads, 8) void k_spmv_tiled(int64_t n_out, int64_t n_in, int64_t tiles, TiledMat Tm,
+static __global__ __launch_bounds__(kTileThreads, 8) void k_spmv_tiled(int64_t n_out, int64_t n_in, int64_t tiles, TiledMat Tm,
                                                                 const double* __restrict__ in, double* __restrict__ part) {
     __shared__ double xs[kTileIn];
     __shared__ double prod[kTileChunk];
@@ -1831,7 +1818,7 @@ __device__ __forceinline__ double tile_pieces_sum(const double* __restrict__ par
     return acc;
 }
 // epilogues of the tiled steps: the pieces in order, then exactly the arithmetic of k_pdhg_x / k_pdhg_y
-__global__ __launch_bounds__(kBlock) void k_x_epilogue(int64_t n, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
+static __global__ __launch_bounds__(kBlock) void k_x_epilogue(int64_t n, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
                                                        double* __restrict__ x, const double* __restrict__ x0, double* __restrict__ xbar,
                                                        const double* __restrict__ c, const double* __restrict__ l,
                                                        const double* __restrict__ u, double tau, double w, double rho) {
@@ -1843,7 +1830,7 @@ __global__ __launch_bounds__(kBlock) void k_x_epilogue(int64_t n, const int32_t*
     xbar[j] = 2.0 * xtv - xv;
     x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0j;
 }
-__global__ __launch_bounds__(kBlock) void k_y_epilogue(int64_t m, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
+static __global__ __launch_bounds__(kBlock) void k_y_epilogue(int64_t m, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
                                                        const int64_t* __restrict__ rowptr, int64_t long_thresh, double* __restrict__ y,
                                                        const double* __restrict__ y0, const double* __restrict__ lo,
                                                        const double* __restrict__ hi, double sigma, double w, double rho) {
@@ -1860,7 +1847,7 @@ __global__ __launch_bounds__(kBlock) void k_y_epilogue(int64_t m, const int32_t*
 // ---- check iteration on the tiled copy: four tiled passes (A'y, A xt, A x, A'yt) with element-wise epilogues; the sums are
 // those of k_pdhg_x<G, false> / k_pdhg_y_chk / k_chk_cols (the CSR check kernels cost 310 us per check on cfg4's large
 // LPs, 4.5 plain iterations; this form 150 us) ------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_x_epilogue_chk(int64_t n, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
+static __global__ __launch_bounds__(kBlock) void k_x_epilogue_chk(int64_t n, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
                                                            const double* __restrict__ x, double* __restrict__ xt,
                                                            const double* __restrict__ c, const double* __restrict__ l,
                                                            const double* __restrict__ u, double tau) {
@@ -1868,13 +1855,13 @@ __global__ __launch_bounds__(kBlock) void k_x_epilogue_chk(int64_t n, const int3
     if (j >= n) return;
     xt[j] = clampd(x[j] - tau * (c[j] - tile_pieces_sum(part, j, n, pcnt)), l[j], u[j]);
 }
-__global__ __launch_bounds__(kBlock) void k_tile_vec(int64_t n_out, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
+static __global__ __launch_bounds__(kBlock) void k_tile_vec(int64_t n_out, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
                                                      double* __restrict__ out) {
     const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (o < n_out) out[o] = tile_pieces_sum(part, o, n_out, pcnt);
 }
 // part holds the pieces of A x, axt_v the vector A xt
-__global__ __launch_bounds__(kBlock) void k_y_epilogue_chk(int64_t m, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
+static __global__ __launch_bounds__(kBlock) void k_y_epilogue_chk(int64_t m, const int32_t* __restrict__ pcnt, const double* __restrict__ part,
                                                            const double* __restrict__ axt_v, const int64_t* __restrict__ rowptr,
                                                            int64_t long_thresh, const double* __restrict__ y, const double* __restrict__ y0,
                                                            double* __restrict__ yt, const double* __restrict__ lo,
@@ -1896,7 +1883,7 @@ __global__ __launch_bounds__(kBlock) void k_y_epilogue_chk(int64_t m, const int3
 
 // ---- building the tiled copy (once per LP solve, after the scaling): count -> scan per (tile, block) -> fill ----------
 // cnt is zeroed, shaped like bptr; thread o owns the shorts [.. + t + 1] of its tile's blocks (no atomics needed)
-__global__ __launch_bounds__(kBlock) void k_tile_count(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+static __global__ __launch_bounds__(kBlock) void k_tile_count(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                        int nb_in, int64_t skip_longer, uint16_t* __restrict__ cnt,
                                                        int32_t* __restrict__ overflow) {
     const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1915,7 +1902,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_count(int64_t n_out, const int6
 }
 // one workgroup per (tile, block): in-place inclusive scan of the kTileOut counts -> offsets; segment total out.
 // Thread t scans the kTilePer CONSECUTIVE counts [t * kTilePer, (t + 1) * kTilePer), then the thread totals are scanned.
-__global__ __launch_bounds__(kTileThreads) void k_tile_scan(uint16_t* __restrict__ cnt, int64_t* __restrict__ segtot,
+static __global__ __launch_bounds__(kTileThreads) void k_tile_scan(uint16_t* __restrict__ cnt, int64_t* __restrict__ segtot,
                                                             int32_t* __restrict__ overflow) {
     __shared__ uint32_t wsum[kTileThreads / 64];
     const int64_t tb = blockIdx.x;
@@ -1942,7 +1929,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scan(uint16_t* __restrict
     for (int k = 0; k < kTilePer; ++k) p[t * kTilePer + k + 1] = (uint16_t)(excl + c[k]);
     if (t == kTileThreads - 1) segtot[tb] = (int64_t)v;
 }
-__global__ __launch_bounds__(kBlock) void k_tile_fill(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+static __global__ __launch_bounds__(kBlock) void k_tile_fill(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                       const double* __restrict__ val, int nb_in, int64_t skip_longer,
                                                       const uint16_t* __restrict__ bptr, uint16_t* __restrict__ cur,
                                                       const int64_t* __restrict__ segstart, uint16_t* __restrict__ tidx,
@@ -1972,7 +1959,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_fill(int64_t n_out, const int64
 // global read-modify-write per entry, the fill one plus two dependent loads (204 + 653 us per orientation on cfg4's LP).  An
 // output that is not ascending sets bit 1 of *overflow; the fill then does nothing and the host repeats the build with the
 // general kernels above.
-__global__ __launch_bounds__(kBlock) void k_tile_count_sorted(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+static __global__ __launch_bounds__(kBlock) void k_tile_count_sorted(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                               int nb_in, int64_t skip_longer, uint16_t* __restrict__ cnt,
                                                               int32_t* __restrict__ overflow) {
     const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1995,7 +1982,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_count_sorted(int64_t n_out, con
     }
     if (prev >= 0) cnt[(tile * nb_in + prev) * (kTileOut + 1) + t + 1] = (uint16_t)run;
 }
-__global__ __launch_bounds__(kBlock) void k_tile_fill_sorted(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+static __global__ __launch_bounds__(kBlock) void k_tile_fill_sorted(int64_t n_out, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                              const double* __restrict__ val, int nb_in, int64_t skip_longer,
                                                              const uint16_t* __restrict__ bptr, const int64_t* __restrict__ segstart,
                                                              const int32_t* __restrict__ overflow, uint16_t* __restrict__ tidx,
@@ -2085,7 +2072,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_stat_skip(int64_t m, const int
     acc = mode ? group_sum<G>(acc) : group_max<G>(acc);
     if (lane == 0) out[i] = dself[i] * acc;
 }
-__global__ __launch_bounds__(1024) void k_scale_stat_long(const int32_t* __restrict__ rows, const int64_t* __restrict__ ptr,
+static __global__ __launch_bounds__(1024) void k_scale_stat_long(const int32_t* __restrict__ rows, const int64_t* __restrict__ ptr,
                                                           const int32_t* __restrict__ idx, const double* __restrict__ val,
                                                           const double* __restrict__ dself, const double* __restrict__ dother,
                                                           int mode, double* __restrict__ out) {
@@ -2105,7 +2092,7 @@ __global__ __launch_bounds__(1024) void k_scale_stat_long(const int32_t* __restr
         out[i] = dself[i] * a;
     }
 }
-__global__ __launch_bounds__(kBlock) void k_scale_apply(int64_t m, double* __restrict__ d, const double* __restrict__ stat) {
+static __global__ __launch_bounds__(kBlock) void k_scale_apply(int64_t m, double* __restrict__ d, const double* __restrict__ stat) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
     const double s = stat[i];
@@ -2115,14 +2102,14 @@ __global__ __launch_bounds__(kBlock) void k_scale_apply(int64_t m, double* __res
 // occurs only in the dense cuts holds nothing but DIFFERENCES of nearly equal derivatives (1e-7 ... rounding noise); the
 // equilibration would blow such a column up by that factor and its cost with it (||c^|| 1e17 seen: primal weight and
 // tolerances meaningless).  A smaller factor than Pock-Chambolle's keeps ||A^||_2 <= 1.  (inf for every other solve.)
-__global__ __launch_bounds__(kBlock) void k_scale_apply2(int64_t m, double* __restrict__ dr, const double* __restrict__ sr, int64_t n,
+static __global__ __launch_bounds__(kBlock) void k_scale_apply2(int64_t m, double* __restrict__ dr, const double* __restrict__ sr, int64_t n,
                                                         double* __restrict__ dc, const double* __restrict__ sc, double cap_c) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < m) { const double s = sr[i]; if (s > 0.0 && isfinite(s)) dr[i] /= sqrt(s); }
     if (i < n) { const double s = sc[i]; if (s > 0.0 && isfinite(s)) dc[i] = fmin(dc[i] / sqrt(s), cap_c); }
 }
 // out[newidx[r]] = in[r] for the kept rows (purge)
-__global__ __launch_bounds__(kBlock) void k_compact_vec(int64_t m, const int64_t* __restrict__ keep, const int64_t* __restrict__ newidx,
+static __global__ __launch_bounds__(kBlock) void k_compact_vec(int64_t m, const int64_t* __restrict__ keep, const int64_t* __restrict__ newidx,
                                                        const double* __restrict__ in, double* __restrict__ out) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r < m && keep[r]) out[newidx[r]] = in[r];
@@ -2143,7 +2130,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_vals(int64_t m, const int64_t*
 // scaled problem vectors
 //   mode 0 (LP):        ch = s c dc,  lh = l/dc, uh = u/dc, xh = clip(x/dc)
 //   mode 1 (recession): ch = s c dc,  box = finite? 0 : -+scale_j  (oracle/lp.py recession_ray)
-__global__ __launch_bounds__(kBlock) void k_prep_cols(int64_t n, const double* __restrict__ c, const double* __restrict__ l,
+static __global__ __launch_bounds__(kBlock) void k_prep_cols(int64_t n, const double* __restrict__ c, const double* __restrict__ l,
                                                       const double* __restrict__ u, const double* __restrict__ dc,
                                                       const double* __restrict__ x, const double* __restrict__ box,
                                                       double sgn, int mode, double* __restrict__ ch,
@@ -2163,7 +2150,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_cols(int64_t n, const double* _
     uh[j] = hi / d;
     xh[j] = clampd((mode == 1 ? 0.0 : x[j]) / d, lo / d, hi / d);
 }
-__global__ __launch_bounds__(kBlock) void k_prep_rows(int64_t m, const double* __restrict__ lo, const double* __restrict__ hi,
+static __global__ __launch_bounds__(kBlock) void k_prep_rows(int64_t m, const double* __restrict__ lo, const double* __restrict__ hi,
                                                       const double* __restrict__ dr, const double* __restrict__ y, int mode,
                                                       double* __restrict__ loh, double* __restrict__ hih,
                                                       double* __restrict__ yh) {
@@ -2181,13 +2168,13 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows(int64_t m, const double* _
     hih[i] = b * d;
     yh[i] = (mode == 1) ? 0.0 : y[i] / d;
 }
-__global__ __launch_bounds__(kBlock) void k_unscale(int64_t n, const double* __restrict__ zh, const double* __restrict__ d,
+static __global__ __launch_bounds__(kBlock) void k_unscale(int64_t n, const double* __restrict__ zh, const double* __restrict__ d,
                                                     double* __restrict__ z) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) z[i] = zh[i] * d[i];
 }
 
-__global__ __launch_bounds__(kBlock) void k_div_vec(int64_t n, const double* __restrict__ a, const double* __restrict__ d,
+static __global__ __launch_bounds__(kBlock) void k_div_vec(int64_t n, const double* __restrict__ a, const double* __restrict__ d,
                                                     double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) out[i] = a[i] / d[i];
@@ -2219,7 +2206,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_skip(int64_t m, SpMat A, const 
     acc = group_sum<G>(acc);
     if (lane == 0) out[i] = acc;
 }
-__global__ __launch_bounds__(1024) void k_spmv_long(const int32_t* __restrict__ rows, SpMat A, const double* __restrict__ v,
+static __global__ __launch_bounds__(1024) void k_spmv_long(const int32_t* __restrict__ rows, SpMat A, const double* __restrict__ v,
                                                     double* __restrict__ out) {
     __shared__ double sh[1024 / 64];
     const int64_t i = rows[blockIdx.x];
@@ -2235,7 +2222,7 @@ __global__ __launch_bounds__(1024) void k_spmv_long(const int32_t* __restrict__ 
     }
 }
 // partials[b] = sum over the block's grid-stride share of a_i * b_i  (b may alias a)
-__global__ __launch_bounds__(kBlock) void k_dot_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+static __global__ __launch_bounds__(kBlock) void k_dot_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
                                                         double* __restrict__ partials) {
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) acc += a[i] * b[i];
@@ -2251,7 +2238,7 @@ __global__ __launch_bounds__(kBlock) void k_dot_partial(int64_t n, const double*
 }
 // partials[b] = sum of log|a_i| (and |b_i|, b optional) over the finite non-zero entries, partials[gridDim + b] = their count:
 // a magnitude statistic that a handful of outliers cannot move (see Engine::lp_solve_core, the initial primal weight)
-__global__ __launch_bounds__(kBlock) void k_logabs_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+static __global__ __launch_bounds__(kBlock) void k_logabs_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
                                                            double* __restrict__ partials) {
     double ls = 0.0, cnt = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
@@ -2270,7 +2257,7 @@ __global__ __launch_bounds__(kBlock) void k_logabs_partial(int64_t n, const doub
     }
 }
 // partials[b] = sum of (a_i d_i)^2: the squared norm of a vector in scaled coordinates without materialising it
-__global__ __launch_bounds__(kBlock) void k_scaled_sq_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ d,
+static __global__ __launch_bounds__(kBlock) void k_scaled_sq_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ d,
                                                               double* __restrict__ partials) {
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) { const double v = a[i] * d[i]; acc += v * v; }
@@ -2284,7 +2271,7 @@ __global__ __launch_bounds__(kBlock) void k_scaled_sq_partial(int64_t n, const d
         partials[blockIdx.x] = v;
     }
 }
-__global__ __launch_bounds__(kRedBlocks) void k_sum_final(const double* __restrict__ partials, int nblocks,
+static __global__ __launch_bounds__(kRedBlocks) void k_sum_final(const double* __restrict__ partials, int nblocks,
                                                           double* __restrict__ out) {
     __shared__ double sh[kRedBlocks / 64];
     double v = ((int)threadIdx.x < nblocks) ? partials[threadIdx.x] : 0.0;
@@ -2297,22 +2284,22 @@ __global__ __launch_bounds__(kRedBlocks) void k_sum_final(const double* __restri
         out[0] = t;
     }
 }
-__global__ __launch_bounds__(kBlock) void k_scale_vec(int64_t n, double* __restrict__ z, double s) {
+static __global__ __launch_bounds__(kBlock) void k_scale_vec(int64_t n, double* __restrict__ z, double s) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) z[i] *= s;
 }
 // out = a / sqrt(*normsq)  (normalisation of the power iteration without a host round trip)
-__global__ __launch_bounds__(kBlock) void k_normalize(int64_t n, const double* __restrict__ a, const double* __restrict__ normsq,
+static __global__ __launch_bounds__(kBlock) void k_normalize(int64_t n, const double* __restrict__ a, const double* __restrict__ normsq,
                                                       double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const double s = normsq[0];
     if (i < n) out[i] = (s > 0.0) ? a[i] / sqrt(s) : 0.0;
 }
-__global__ __launch_bounds__(kBlock) void k_fill(int64_t n, double* __restrict__ z, double v) {
+static __global__ __launch_bounds__(kBlock) void k_fill(int64_t n, double* __restrict__ z, double v) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) z[i] = v;
 }
-__global__ __launch_bounds__(kBlock) void k_axpy_scaled(int64_t n, const double* __restrict__ a, double s, double* __restrict__ out) {
+static __global__ __launch_bounds__(kBlock) void k_axpy_scaled(int64_t n, const double* __restrict__ a, double s, double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) out[i] = a[i] * s;
 }
@@ -2341,7 +2328,7 @@ __global__ __launch_bounds__(kBlock) void k_csc_keys(int64_t m, const int64_t* _
 // solve on cfg3) the old columns are shifted by the running count of new entries and the new entries dropped in behind
 // them.  The mirror keeps, per position, the CSR entry it came from (perm): values are gathered through it, which is also
 // what lets the epigraph-shifted working form refresh its values without touching the structure.
-__global__ __launch_bounds__(kBlock) void k_cscm_count(int64_t e0, int64_t nnz, const int32_t* __restrict__ col, int64_t* __restrict__ cnt) {
+static __global__ __launch_bounds__(kBlock) void k_cscm_count(int64_t e0, int64_t nnz, const int32_t* __restrict__ col, int64_t* __restrict__ cnt) {
     const int64_t e = e0 + (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e < nnz) atomicAdd(reinterpret_cast<unsigned long long*>(&cnt[col[e]]), 1ULL);
 }
@@ -2378,7 +2365,7 @@ __global__ __launch_bounds__(kBlock) void k_cscm_place(int64_t m0, int64_t m, co
 }
 // ... and put into row order column by column (a column gets 0.3 new entries per sweep on average: an insertion sort of a
 // handful), so that every column sum keeps its fixed order whatever the arrival order was
-__global__ __launch_bounds__(kBlock) void k_cscm_order(int64_t n, const int64_t* __restrict__ old_ptr, const int64_t* __restrict__ off,
+static __global__ __launch_bounds__(kBlock) void k_cscm_order(int64_t n, const int64_t* __restrict__ old_ptr, const int64_t* __restrict__ off,
                                                        int32_t* __restrict__ new_row, uint32_t* __restrict__ new_perm) {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= n) return;
@@ -2395,12 +2382,12 @@ __global__ __launch_bounds__(kBlock) void k_cscm_order(int64_t n, const int64_t*
         new_row[b + q + 1] = rr; new_perm[b + q + 1] = pp;
     }
 }
-__global__ __launch_bounds__(kBlock) void k_csc_vals(int64_t nnz, const uint32_t* __restrict__ perm, const double* __restrict__ val,
+static __global__ __launch_bounds__(kBlock) void k_csc_vals(int64_t nnz, const uint32_t* __restrict__ perm, const double* __restrict__ val,
                                                      double* __restrict__ cval) {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p < nnz) cval[p] = val[perm[p]];
 }
-__global__ __launch_bounds__(kBlock) void k_csc_rows_perm(int64_t nnz, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ perm,
+static __global__ __launch_bounds__(kBlock) void k_csc_rows_perm(int64_t nnz, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ perm,
                                                           int32_t* __restrict__ crow, uint32_t* __restrict__ cperm) {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= nnz) return;
@@ -2413,7 +2400,7 @@ __global__ __launch_bounds__(kBlock) void k_csc_rows_perm(int64_t nnz, const uin
 // layout katana_jl_amd/distributed.py::pack_block uses on the host path.  The block never leaves device memory: the engine
 // writes it into the caller's send buffer, RCCL all-gathers it, the engine appends every rank's block from the receive
 // buffers (ktn_lp_pack_rows_dev / ktn_lp_append_packed_dev).
-__global__ __launch_bounds__(kBlock) void k_pack_rows(int64_t nr, int64_t nz, const int64_t* __restrict__ rowptr /* at first_row */,
+static __global__ __launch_bounds__(kBlock) void k_pack_rows(int64_t nr, int64_t nz, const int64_t* __restrict__ rowptr /* at first_row */,
                                                       const int32_t* __restrict__ col, const double* __restrict__ val /* at base */,
                                                       const double* __restrict__ lo, const double* __restrict__ hi,
                                                       const int32_t* __restrict__ slots, int64_t id_offset, double* __restrict__ out) {
@@ -2430,7 +2417,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_rows(int64_t nr, int64_t nz, co
         out[nr + nz + i] = val[i];
     }
 }
-__global__ __launch_bounds__(kBlock) void k_unpack_rows(int64_t nr, int64_t nz, const double* __restrict__ in, int64_t nnz0,
+static __global__ __launch_bounds__(kBlock) void k_unpack_rows(int64_t nr, int64_t nz, const double* __restrict__ in, int64_t nnz0,
                                                         int64_t n_lp, int64_t* __restrict__ rowptr /* at M + 1 */,
                                                         int32_t* __restrict__ col, double* __restrict__ val /* at nnz0 */,
                                                         double* __restrict__ lo, double* __restrict__ hi /* at M */,
@@ -2453,7 +2440,7 @@ __global__ __launch_bounds__(kBlock) void k_unpack_rows(int64_t nr, int64_t nz, 
 }
 
 // recession-LP box of the epigraph variable: 1 + max_r sum_{j != aux} |a_rj| / |a_r,aux|
-__global__ __launch_bounds__(kBlock) void k_aux_box(int64_t m, const int64_t* __restrict__ rowptr,
+static __global__ __launch_bounds__(kBlock) void k_aux_box(int64_t m, const int64_t* __restrict__ rowptr,
                                                     const int32_t* __restrict__ col, const double* __restrict__ val,
                                                     int32_t aux, double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -2480,7 +2467,7 @@ __global__ __launch_bounds__(kBlock) void k_aux_box(int64_t m, const int64_t* __
 // complementarity error of the LP solve, which its gap accounts for.
 // The engine evaluates this sum and keeps cutting below f_tol while it exceeds the objective tolerance the reference's tests
 // ask for (test/runtests.jl:16-17) -- the refinement that used to be tied to problems of at most 32 columns.
-__global__ __launch_bounds__(kBlock) void k_cert_nl(int64_t m_nl, const int32_t* __restrict__ nl_rows, const int64_t* __restrict__ last_cut,
+static __global__ __launch_bounds__(kBlock) void k_cert_nl(int64_t m_nl, const int32_t* __restrict__ nl_rows, const int64_t* __restrict__ last_cut,
                                                     const int64_t* __restrict__ cut_prev, const double* __restrict__ y,
                                                     const double* __restrict__ g, const double* __restrict__ lb,
                                                     const double* __restrict__ ub, double f_tol, double* __restrict__ out) {
@@ -2498,7 +2485,7 @@ __global__ __launch_bounds__(kBlock) void k_cert_nl(int64_t m_nl, const int32_t*
 // workgroup b adds up the shares of the NL slots whose row lives in block b's columns (fixed order: deterministic) and the
 // block's own objective c_b'x_b, and writes  out[b] = D_b / target_b  (target_b = tol * max(1, |obj_b|))  and
 // out[nb + b] = target_b / (1 + 2 |obj_b|)  (the relative LP gap a quarter of which the refinement solves ask for).
-__global__ __launch_bounds__(kBlock) void k_cert_blocks(int64_t m_nl, const int32_t* __restrict__ nl_rows, const int64_t* __restrict__ rowptr,
+static __global__ __launch_bounds__(kBlock) void k_cert_blocks(int64_t m_nl, const int32_t* __restrict__ nl_rows, const int64_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col, const double* __restrict__ cert,
                                                         const int64_t* __restrict__ blk_col, int64_t nb, const double* __restrict__ c,
                                                         const double* __restrict__ x, double tol, double* __restrict__ out) {
@@ -2527,7 +2514,7 @@ __global__ __launch_bounds__(kBlock) void k_cert_blocks(int64_t m_nl, const int3
     }
 }
 // partials[b] = sum over the block's grid-stride share of a_i
-__global__ __launch_bounds__(kBlock) void k_sum_partial(int64_t n, const double* __restrict__ a, double* __restrict__ partials) {
+static __global__ __launch_bounds__(kBlock) void k_sum_partial(int64_t n, const double* __restrict__ a, double* __restrict__ partials) {
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) acc += a[i];
     __shared__ double sh[kBlock / 64];
@@ -2552,7 +2539,7 @@ __global__ __launch_bounds__(kBlock) void k_sum_partial(int64_t n, const double*
 // vector and the rows hold only the differences.  The stored LP (lp_val, lp_lo, lp_hi, lp_c: what getKatanaCuts exports,
 // what purging and the exact small-LP kernel read) stays in the reference's form; the solve reads the working copies.
 // An epigraph cut is recognised by its last entry: the epigraph variable has the largest column index (engine.hip, loadproblem).
-__global__ __launch_bounds__(kBlock) void k_epi_newest(int64_t first, int64_t m, const int64_t* __restrict__ rowptr,
+static __global__ __launch_bounds__(kBlock) void k_epi_newest(int64_t first, int64_t m, const int64_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ col, int32_t tcol,
                                                        unsigned long long* __restrict__ newest_plus1) {
     const int64_t r = first + (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -2561,7 +2548,7 @@ __global__ __launch_bounds__(kBlock) void k_epi_newest(int64_t first, int64_t m,
     if (end > rowptr[r] && col[end - 1] == tcol) atomicMax(newest_plus1, (unsigned long long)(r + 1));
 }
 // a_ref (dense, zero-initialised by the caller) and b_ref from the newest epigraph cut; scal[0] = b_ref, scal[1] = a_ref'x (later)
-__global__ __launch_bounds__(kBlock) void k_epi_setref(const unsigned long long* __restrict__ newest_plus1,
+static __global__ __launch_bounds__(kBlock) void k_epi_setref(const unsigned long long* __restrict__ newest_plus1,
                                                        const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                        const double* __restrict__ val, const double* __restrict__ lo,
                                                        const double* __restrict__ hi, int32_t tcol, double* __restrict__ aref,
@@ -2584,7 +2571,7 @@ __global__ __launch_bounds__(kBlock) void k_epi_setref(const unsigned long long*
 }
 // working copies of the epigraph cuts: kEpiChunks workgroups per LP row from `first` on (all others return at once)
 constexpr int kEpiChunks = 16;
-__global__ __launch_bounds__(kBlock) void k_epi_shift(int64_t first, int64_t m, const int64_t* __restrict__ rowptr,
+static __global__ __launch_bounds__(kBlock) void k_epi_shift(int64_t first, int64_t m, const int64_t* __restrict__ rowptr,
                                                       const int32_t* __restrict__ col, const double* __restrict__ val,
                                                       const double* __restrict__ lo, const double* __restrict__ hi, int32_t tcol,
                                                       const double* __restrict__ aref, const double* __restrict__ scal,
@@ -2604,7 +2591,7 @@ __global__ __launch_bounds__(kBlock) void k_epi_shift(int64_t first, int64_t m, 
     if (chunk == 0 && threadIdx.x == 0) { wlo[r] = lo[r] + scal[0]; whi[r] = hi[r] + scal[0]; }
 }
 // working cost: c_x + c_t a_ref  (a_ref[tcol] == 0)
-__global__ __launch_bounds__(kBlock) void k_epi_cost(int64_t n, const double* __restrict__ c, int32_t tcol,
+static __global__ __launch_bounds__(kBlock) void k_epi_cost(int64_t n, const double* __restrict__ c, int32_t tcol,
                                                      const double* __restrict__ aref, double* __restrict__ wc) {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j < n) wc[j] = c[j] + c[tcol] * aref[j];
@@ -2616,7 +2603,7 @@ __global__ __launch_bounds__(kBlock) void k_epi_cost(int64_t n, const double* __
 //             drifts back at the pace of the primal step.  first = 1 (no earlier solve): s = 0, i.e. t starts AT the
 //             reference cut's value -- from t = 0 it would have to travel |a_ref'x + b_ref| the same way.
 //   dir = +1: x[tcol]  += a_ref'x + b_ref                (x unscaled, after the solve)
-__global__ void k_epi_var(double* __restrict__ x, int32_t tcol, const double* __restrict__ scal, const double* __restrict__ d, int dir,
+static __global__ void k_epi_var(double* __restrict__ x, int32_t tcol, const double* __restrict__ scal, const double* __restrict__ d, int dir,
                           int first, double sgn, const unsigned long long* __restrict__ newest_plus1) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const double off = scal[1] + scal[0];
@@ -2630,6 +2617,33 @@ __global__ void k_epi_var(double* __restrict__ x, int32_t tcol, const double* __
     } else {
         x[tcol] += off;
     }
+}
+
+// ---- two small helpers of the LP setup (sum of squares over the finite entries; hashed start vector of the power iteration)
+static __global__ __launch_bounds__(kBlock) void k_finite_sq_partial(int64_t n, const double* __restrict__ a,
+                                                              double* __restrict__ partials) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double v = a[i];
+        if (isfinite(v)) acc += v * v;
+    }
+    __shared__ double sh[kBlock / 64];
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = 0.0;
+        for (int k = 0; k < kBlock / 64; ++k) v += sh[k];
+        partials[blockIdx.x] = v;
+    }
+}
+
+static __global__ __launch_bounds__(kBlock) void k_hash_fill(int64_t n, double* __restrict__ z) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint64_t h = (uint64_t)i * 0x9E3779B97F4A7C15ULL + 0xD1B54A32D192ED03ULL;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+    z[i] = 0.25 + (double)(h >> 11) * (1.0 / 9007199254740992.0);   // in [0.25, 1.25)
 }
 
 }  // namespace ktn

@@ -83,7 +83,7 @@ __device__ __forceinline__ double mid_row_rhs(const MidLpIO& P, int k) {
 }
 
 // bound vertex the cost pushes to: B = diag(+-1) is its own inverse
-__global__ __launch_bounds__(256) void k_mid_init(MidLpIO P) {
+static __global__ __launch_bounds__(256) void k_mid_init(MidLpIO P) {
     const int n = P.n;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx < (int64_t)n * n) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_mid_init(MidLpIO P) {
 // thread each.  (Measured and NOT kept, round 4: the whole pivot in one 1 024-thread workgroup -- 35 us, pricing 2.7 MB through one
 // CU's L2 port; pricing + one fused single-workgroup launch for the rest -- 42 us with the rank-one update inside it (a 50-trip
 // dependent loop per thread), 26 - 29 us with the rank-one update as a third launch: no better than these five small launches.)
-__global__ __launch_bounds__(256) void k_mid_price(MidLpIO P) {
+static __global__ __launch_bounds__(256) void k_mid_price(MidLpIO P) {
     __shared__ double sv[256];
     __shared__ int si[256];
     const int t = threadIdx.x;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_mid_price(MidLpIO P) {
 }
 
 // final argmax, the stop test, and the entering side's excess g_q'x - h_q
-__global__ __launch_bounds__(256) void k_mid_select(MidLpIO P) {
+static __global__ __launch_bounds__(256) void k_mid_select(MidLpIO P) {
     __shared__ double sv[256];
     __shared__ int si[256];
     MidState* st = P.st;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_mid_select(MidLpIO P) {
 }
 
 // u = B^-T g_q: only the rows of B^-1 in the support of g_q
-__global__ __launch_bounds__(256) void k_mid_u(MidLpIO P) {
+static __global__ __launch_bounds__(256) void k_mid_u(MidLpIO P) {
     if (P.st->status != 0) return;
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= P.n) return;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_mid_u(MidLpIO P) {
 }
 
 // ratio test, then the updates of x, lambda, W (the rank-one update of B^-1 follows in k_mid_rank1)
-__global__ __launch_bounds__(256) void k_mid_ratio(MidLpIO P) {
+static __global__ __launch_bounds__(256) void k_mid_ratio(MidLpIO P) {
     __shared__ double sv[256];
     __shared__ int si[256];
     __shared__ int s_art;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_mid_ratio(MidLpIO P) {
 }
 
 // B^-1 <- B^-1 - d (u - e_p)' / u_p
-__global__ __launch_bounds__(256) void k_mid_rank1(MidLpIO P) {
+static __global__ __launch_bounds__(256) void k_mid_rank1(MidLpIO P) {
     const MidState* st = P.st;
     // runs exactly when k_mid_ratio of this pivot pivoted: k_mid_price cleared `p`, only a pivot sets it
     if (st->p < 0) return;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_mid_rank1(MidLpIO P) {
 
 // ---- refinement: x and lambda from their definitions ------------------------------------------------------------
 // rvec_r = h_r - b_r'x over the working sides (x = nullptr: rvec = h_W)
-__global__ __launch_bounds__(256) void k_mid_resid(MidLpIO P, int use_x) {
+static __global__ __launch_bounds__(256) void k_mid_resid(MidLpIO P, int use_x) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= P.n) return;
     const int k = P.W[r];
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_mid_resid(MidLpIO P, int use_x) {
     P.rvec[r] = P.hW[r] - acc;
 }
 // x_j (+)= sum_r Binv[j][r] rvec_r: one wavefront per j
-__global__ __launch_bounds__(256) void k_mid_apply(MidLpIO P, int accumulate) {
+static __global__ __launch_bounds__(256) void k_mid_apply(MidLpIO P, int accumulate) {
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= P.n) return;
     const double* row = P.Binv + (int64_t)j * P.n;
@@ -350,16 +350,16 @@ __global__ __launch_bounds__(256) void k_mid_apply(MidLpIO P, int accumulate) {
     if (lane == 0) P.x[j] = accumulate ? P.x[j] + acc : acc;
 }
 // lambda_r = -sum_j Binv[j][r] s c_j (coalesced over r), clamped at 0
-__global__ __launch_bounds__(256) void k_mid_lambda(MidLpIO P) {
+static __global__ __launch_bounds__(256) void k_mid_lambda(MidLpIO P) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= P.n) return;
     double acc = 0.0;
     for (int j = 0; j < P.n; ++j) acc += P.Binv[(int64_t)j * P.n + r] * P.ctil[j];
     P.lam[r] = fmax(-acc, 0.0);
 }
-__global__ void k_mid_rearm(MidState* st) { st->status = 0; st->pivots = 0; st->degen_run = 0; st->art_left = 0; st->p = -1; st->gj_singular = 0; }
+static __global__ void k_mid_rearm(MidState* st) { st->status = 0; st->pivots = 0; st->degen_run = 0; st->art_left = 0; st->p = -1; st->gj_singular = 0; }
 // max |rvec| into st->resid, and back to "running" for the confirming price
-__global__ __launch_bounds__(256) void k_mid_resid_norm(MidLpIO P, int rearm) {
+static __global__ __launch_bounds__(256) void k_mid_resid_norm(MidLpIO P, int rearm) {
     __shared__ double sv[256];
     const int t = threadIdx.x;
     double m = 0.0;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_mid_resid_norm(MidLpIO P, int rearm) {
 }
 
 // outputs: row multipliers in the engine's convention (> 0 lower side, < 0 upper side), objective, leftover artificial sides
-__global__ __launch_bounds__(256) void k_mid_final(MidLpIO P, double* y) {
+static __global__ __launch_bounds__(256) void k_mid_final(MidLpIO P, double* y) {
     __shared__ double sv[256];
     __shared__ int s_art;
     const int t = threadIdx.x, n = P.n;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void k_mid_final(MidLpIO P, double* y) {
 // whose inverse is older than that -- B is rebuilt from W into [B | I] and inverted by Gauss-Jordan with partial pivoting,
 // one column per step (four small launches: pivot search, row swap + scaling, column extract, elimination: n = 512 -> 10 ms).
 constexpr int kMidRefactor = 1500;
-__global__ __launch_bounds__(256) void k_mid_gj_build(MidLpIO P, double* __restrict__ aug) {      // aug: n x 2n, row r = [normal of W_r | e_r]
+static __global__ __launch_bounds__(256) void k_mid_gj_build(MidLpIO P, double* __restrict__ aug) {      // aug: n x 2n, row r = [normal of W_r | e_r]
     const int n = P.n;
     const int r = blockIdx.x;
     double* row = aug + (int64_t)r * 2 * n;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_mid_gj_build(MidLpIO P, double* __restr
     }
     if (r == 0 && threadIdx.x == 0) P.st->gj_singular = 0;
 }
-__global__ __launch_bounds__(256) void k_mid_gj_pivot(MidLpIO P, const double* __restrict__ aug, int col) {
+static __global__ __launch_bounds__(256) void k_mid_gj_pivot(MidLpIO P, const double* __restrict__ aug, int col) {
     __shared__ double sv[256];
     __shared__ int si[256];
     const int n = P.n, t = threadIdx.x;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void k_mid_gj_pivot(MidLpIO P, const double* _
     }
 }
 // swap rows col <-> p, and the scaled pivot row into prow
-__global__ __launch_bounds__(256) void k_mid_gj_swap(MidLpIO P, double* __restrict__ aug, int col, double* __restrict__ prow) {
+static __global__ __launch_bounds__(256) void k_mid_gj_swap(MidLpIO P, double* __restrict__ aug, int col, double* __restrict__ prow) {
     const int n = P.n;
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= 2 * n || P.st->gj_singular) return;
@@ -450,12 +450,12 @@ __global__ __launch_bounds__(256) void k_mid_gj_swap(MidLpIO P, double* __restri
     if (p != col) aug[(int64_t)p * 2 * n + q] = a;
     prow[q] = b / P.st->gj_piv;
 }
-__global__ __launch_bounds__(256) void k_mid_gj_col(MidLpIO P, const double* __restrict__ aug, int col, double* __restrict__ fcol) {
+static __global__ __launch_bounds__(256) void k_mid_gj_col(MidLpIO P, const double* __restrict__ aug, int col, double* __restrict__ fcol) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= P.n || P.st->gj_singular) return;
     fcol[r] = aug[(int64_t)r * 2 * P.n + col];
 }
-__global__ __launch_bounds__(256) void k_mid_gj_elim(MidLpIO P, double* __restrict__ aug, int col, const double* __restrict__ prow,
+static __global__ __launch_bounds__(256) void k_mid_gj_elim(MidLpIO P, double* __restrict__ aug, int col, const double* __restrict__ prow,
                                                      const double* __restrict__ fcol) {
     const int n = P.n;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_mid_gj_elim(MidLpIO P, double* __restri
     const int r = (int)(idx / (2 * n)), q = (int)(idx % (2 * n));
     aug[idx] = (r == col) ? prow[q] : aug[idx] - fcol[r] * prow[q];
 }
-__global__ __launch_bounds__(256) void k_mid_gj_store(MidLpIO P, const double* __restrict__ aug) {
+static __global__ __launch_bounds__(256) void k_mid_gj_store(MidLpIO P, const double* __restrict__ aug) {
     const int n = P.n;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)n * n || P.st->gj_singular) return;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void k_mid_gj_store(MidLpIO P, const double* _
 }
 
 // after a purge: working rows move to their new indices; a working row that was dropped voids the warm start
-__global__ __launch_bounds__(256) void k_mid_remap(int n, int32_t* W, const int64_t* __restrict__ keep, const int64_t* __restrict__ newidx,
+static __global__ __launch_bounds__(256) void k_mid_remap(int n, int32_t* W, const int64_t* __restrict__ keep, const int64_t* __restrict__ newidx,
                                                    int32_t* __restrict__ lost) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;

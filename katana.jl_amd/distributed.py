@@ -8,7 +8,7 @@ The cuts are then all-gathered -- two collectives per iteration: the (rows, nnz)
 status flags and the largest violation, then the cut blocks padded to the largest -- and appended on every rank in RANK ORDER, so that all
 ranks hold the identical LP and the deterministic GPU LP gives them the identical x*.
 
-The loop below is the host-level statement of Engine::step (csrc/engine.hip) with the exchange
+The loop below is the host-level statement of Engine::step (csrc/ecp.hip) with the exchange
 between sweep and append; it drives the same kernels through the C ABI.
 """
 import numpy as np

@@ -289,7 +289,7 @@ def solve_lp_halpern(A, c, l, u, lo, hi, x0=None, y0=None, params=None, omega0=N
     restart on the fixed-point residual r(z) = ||z - PDHG(z)||_M,
     M = [[omega/eta I, -A'], [-A, 1/(eta omega) I]].
 
-    The product adds two safeguards that need state this mirror does not have (csrc/engine.hip
+    The product adds two safeguards that need state this mirror does not have (csrc/lp.hip
     lp_solve): backing eta off when the residual stops moving, and moving multiplier mass between
     the cuts of one nonlinear row when PDHG idles between two near-parallel cuts (k_consolidate).
     """

@@ -1,6 +1,6 @@
 /* Host-side AddressSanitizer harness of the C-ABI layer (SURVEY.md section 5 "race detection / sanitizers": the reference
  * is serial Julia and has none; the build plan asks for a -fsanitize=address host harness).  Built by `make asan` against
- * libkatana_hip_asan.so (host code of csrc/engine.hip instrumented, device code untouched) and run on the CPU box, where
+ * libkatana_hip_asan.so (host code of the csrc units instrumented, device code untouched) and run on the CPU box, where
  * ktn_create refuses with KTN_E_NODEVICE: what runs under the sanitizer is the layer every binding goes through first --
  * parameter defaults, handle creation and its failure path, and the argument validation of every entry point (NULL
  * handles, NULL output pointers), none of which may read or write through what it was given.
