@@ -6,7 +6,7 @@
 //   ecp.hip     the cutting-plane loop: begin / step / polish_step / end, objective certificate, device-side batch loop
 //   dist.hip    collectives of the row-sharded LP: RCCL, peer buffers, host callback
 //   abi.hip     the C ABI of include/katana_hip.h
-// (until round 3 all of it was engine.hip, one translation unit of 4 100 lines).
+// (until the middle of round 4 all of it was engine.hip, one translation unit of 4 100 lines).
 //
 // Mirrors, function by function, the reference's driver (src/model.jl) with every piece of
 // arithmetic on the device:

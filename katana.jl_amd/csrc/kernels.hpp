@@ -1054,16 +1054,26 @@ struct ChkAcc {
 // written as zeros without being reduced).
 constexpr unsigned kChkRowMask = 0x141Fu;     // s0-s4, s10, m12
 constexpr unsigned kChkColMask = 0x6FE0u;     // s5-s11, m13, m14
-template <int BLOCK, unsigned MASK>
+// G: only the first lane of every G-lane group carries a value (the others hold the zeros of init()), so the butterfly's last log2 G
+// steps would add zeros and are left out.  The steps run quantity-interleaved -- one step of all chains, then the next -- so that
+// the cross-lane latencies of the (up to nine) chains overlap instead of queueing behind each other; same sums, same order.
+template <int BLOCK, unsigned MASK, int G = 1>
 __device__ __forceinline__ void chk_block_store(ChkAcc& a, double* partials) {
     __shared__ double sh[kChkQ][BLOCK / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int q = 0; q < kChkQ; ++q) {
-        if (!((MASK >> q) & 1u)) continue;
-        double v = a.s[q];
-        if (q < 12) v = group_sum<64>(v); else v = group_max<64>(v);
-        if (lane == 0) sh[q][wv] = v;
+    for (int off = 32; off >= G; off >>= 1) {
+#pragma unroll
+        for (int q = 0; q < kChkQ; ++q) {
+            if (!((MASK >> q) & 1u)) continue;
+            const double o = __shfl_xor(a.s[q], off, 64);
+            a.s[q] = (q < 12) ? a.s[q] + o : fmax(a.s[q], o);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < kChkQ; ++q)
+            if ((MASK >> q) & 1u) sh[q][wv] = a.s[q];
     }
     __syncthreads();
     if (threadIdx.x < kChkQ) {
@@ -1372,7 +1382,7 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_y_chk(int64_t m, SpMat A, const
         yt[i] = ytv;
         chk_row_accumulate(a, ytv, yv, y0i, axt, axk, loi, hii, dri);
     }
-    chk_block_store<kBlock, kChkRowMask>(a, partials);
+    chk_block_store<kBlock, kChkRowMask, G>(a, partials);
 }
 
 // Long rows (dense epigraph cuts: n+1 entries): one 1024-thread workgroup per row, fixed-shape
@@ -1526,7 +1536,7 @@ __global__ __launch_bounds__(kBlock) void k_chk_cols(int64_t n, SpMat AT, const 
         if (r0 > 0.0) { if (isfinite(lj)) { a.s[10] += lj * r0; a.s[11] += fabs(lj * r0); } else a.s[14] = fmax(a.s[14], r0); }
         else if (r0 < 0.0) { if (isfinite(uj)) { a.s[10] += uj * r0; a.s[11] += fabs(uj * r0); } else a.s[14] = fmax(a.s[14], -r0); }
     }
-    chk_block_store<kBlock, kChkColMask>(a, partials);
+    chk_block_store<kBlock, kChkColMask, G>(a, partials);
 }
 
 // ================================================== LP: row-sharded over several GPUs ===============================
