@@ -519,7 +519,10 @@ struct Engine {
     bool recession_ray_dense(bool* unbounded);
     void launch_y(const SpMat& A, double sigma, double w, double rho, hipEvent_t e0, hipEvent_t e1);
     void launch_x(const SpMat& AT, double tau, double w, double rho, bool update, hipEvent_t e0, hipEvent_t e1);
-    void launch_check(const SpMat& A, const SpMat& AT, double tau, double sigma);
+    // w_next >= 0: the check kernels also write the Halpern update of this iteration into xnext / ynext (returns true when they did:
+    // the plain CSR form only); the caller swaps them in for x / y instead of launching k_halpern2
+    bool launch_check(const SpMat& A, const SpMat& AT, double tau, double sigma, double w_next = -1.0, double rho = 1.0);
+    DBuf<double> xnext, ynext;
     int chk_nrow = 0, chk_ncol = 0;     // partial blocks of the last check (rows | columns)
     void compute_scaling(bool identity);
     LpResult lp_solve(double tol_p, double tol_g, int mode, bool identity_scaling = false);

@@ -1103,14 +1103,19 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_x(int64_t n, SpMat AT, const do
     const int64_t beg = AT.ptr[j], end = AT.ptr[j + 1];
     // the per-column scalars are requested up front by every lane of the group (same address: one
     // transaction), so their latency overlaps the gather chain instead of following the reduction
-    const double xv = x[j], cj = c[j], lj = l[j], uj = u[j], x0j = UPDATE ? x0[j] : 0.0;
+    // (check form with xbar != nullptr: the slot receives the Halpern update the iteration WOULD make -- if the host decides to go
+    //  on, it swaps that array in for x instead of launching k_halpern2; same expression, same bits)
+    const double xv = x[j], cj = c[j], lj = l[j], uj = u[j], x0j = (UPDATE || xbar) ? x0[j] : 0.0;
     double acc = 0.0;
     for (int64_t e = beg + lane; e < end; e += G) acc += AT.val[e] * y[AT.idx[e]];
     acc = group_sum<G>(acc);
     if (lane == 0) {
         const double xtv = clampd(xv - tau * (cj - acc), lj, uj);
         if (UPDATE) { xbar[j] = 2.0 * xtv - xv; x[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0j; }
-        else xt[j] = xtv;
+        else {
+            xt[j] = xtv;
+            if (xbar) xbar[j] = w * ((1.0 + rho) * xtv - rho * xv) + (1.0 - w) * x0j;
+        }
     }
 }
 
@@ -1357,7 +1362,7 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_y_chk(int64_t m, SpMat A, const
                                                        const double* __restrict__ y0, double* __restrict__ yt,
                                                        const double* __restrict__ lo, const double* __restrict__ hi,
                                                        const double* __restrict__ dr, double sigma, int64_t long_thresh,
-                                                       double* __restrict__ partials) {
+                                                       double* __restrict__ partials, double* __restrict__ ynext, double w, double rho) {
     const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
     const int lane = threadIdx.x & (G - 1);
     ChkAcc a; a.init();
@@ -1380,6 +1385,7 @@ __global__ __launch_bounds__(kBlock) void k_pdhg_y_chk(int64_t m, SpMat A, const
         const double v = yv - sigma * (2.0 * axt - axk);
         const double ytv = v + sigma * clampd(-v / sigma, loi, hii);
         yt[i] = ytv;
+        if (ynext) ynext[i] = w * ((1.0 + rho) * ytv - rho * yv) + (1.0 - w) * y0i;      // (see k_pdhg_x: the update the iteration would make)
         chk_row_accumulate(a, ytv, yv, y0i, axt, axk, loi, hii, dri);
     }
     chk_block_store<kBlock, kChkRowMask, G>(a, partials);
@@ -2042,26 +2048,42 @@ __global__ __launch_bounds__(kBlock) void k_scale_stat(int64_t m, const int64_t*
 // statistic and update in one launch: dnew_i = dself_i / sqrt(dself_i * stat_i) (unchanged where the statistic is 0 or not
 // finite) -- the arithmetic of k_scale_stat followed by k_scale_apply2, without the third launch of every pass.  Rows and
 // columns both read the OLD scalings and write new arrays, which the host swaps in after the pass.
-template <int G>
-__global__ __launch_bounds__(kBlock) void k_scale_stat_upd(int64_t m, const int64_t* __restrict__ ptr,
-                                                           const int32_t* __restrict__ idx, const double* __restrict__ val,
-                                                           const double* __restrict__ dself, const double* __restrict__ dother,
-                                                           int mode, double* __restrict__ dnew, double cap) {
-    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
-    const int lane = threadIdx.x & (G - 1);
+// ... and both sides of a pass in ONE launch: they do not depend on each other -- blocks [0, br) take the rows with gr lanes each, the
+// rest the columns with gc lanes (lane counts at run time; the butterfly runs in the order of group_sum / group_max: the same bits as
+// the one-side-per-launch form of rounds 2-4).  Nine launches and nine kernel boundaries less per LP solve.  (cap: see k_scale_apply2.)
+__device__ __forceinline__ void scale_stat_upd_side(int64_t t, int g, int64_t m, const int64_t* __restrict__ ptr,
+                                                    const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                    const double* __restrict__ dself, const double* __restrict__ dother,
+                                                    int mode, double* __restrict__ dnew, double cap) {
+    const int64_t i = t / g;
+    const int lane = (int)(t & (g - 1));
     if (i >= m) return;
     double acc = 0.0;
-    for (int64_t e = ptr[i] + lane; e < ptr[i + 1]; e += G) {
+    for (int64_t e = ptr[i] + lane; e < ptr[i + 1]; e += g) {
         const double v = fabs(val[e]) * dother[idx[e]];
         acc = mode ? acc + v : fmax(acc, v);
     }
-    acc = mode ? group_sum<G>(acc) : group_max<G>(acc);
+    for (int off = g >> 1; off > 0; off >>= 1) {
+        const double o = __shfl_xor(acc, off, 64);
+        acc = mode ? acc + o : fmax(acc, o);
+    }
     if (lane == 0) {
         double d = dself[i];
         const double st = d * acc;
         if (st > 0.0 && isfinite(st)) d /= sqrt(st);
-        dnew[i] = fmin(d, cap);         // (cap: see k_scale_apply2)
+        dnew[i] = fmin(d, cap);
     }
+}
+static __global__ __launch_bounds__(kBlock) void k_scale_stat_upd_both(int64_t m, const int64_t* __restrict__ rptr, const int32_t* __restrict__ ridx,
+                                                                const double* __restrict__ rval, int64_t n, const int64_t* __restrict__ cptr,
+                                                                const int32_t* __restrict__ cidx, const double* __restrict__ cval,
+                                                                const double* __restrict__ dr, const double* __restrict__ dc, int mode,
+                                                                double* __restrict__ dr_new, double* __restrict__ dc_new, double cap_c,
+                                                                int gr, int gc, int br) {
+    if ((int)blockIdx.x < br)
+        scale_stat_upd_side((int64_t)blockIdx.x * kBlock + threadIdx.x, gr, m, rptr, ridx, rval, dr, dc, mode, dr_new, __builtin_inf());
+    else
+        scale_stat_upd_side((int64_t)(blockIdx.x - br) * kBlock + threadIdx.x, gc, n, cptr, cidx, cval, dc, dr, mode, dc_new, cap_c);
 }
 // the same with the long rows left to k_scale_stat_long (one 1024-thread workgroup per long row)
 template <int G>

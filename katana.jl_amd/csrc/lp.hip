@@ -74,10 +74,11 @@ void Engine::compute_scaling(bool identity) {
                 KTN_HIP(hipMemcpyAsync(dc_r.p, dc.p, (size_t)n_lp * sizeof(double), hipMemcpyDeviceToDevice, stream));
             }
             if (n_long == 0 && n_longc == 0 && !row_sharded() && M > 0) {
-                // statistic + update in one launch per side, into new arrays that are swapped in (22 launches instead of 33)
+                // statistic + update of BOTH sides in one launch, into new arrays that are swapped in (9 launches; round 1: 33, round 2: 22)
                 dr2.resize((size_t)M, stream); dc2.resize((size_t)n_lp, stream);
-                LAUNCH_G(gr, k_scale_stat_upd, M, stream, M, lp_rowptr.p, lp_col.p, Wval(), dr.p, dc.p, mode, dr2.p, kInf);
-                LAUNCH_G(gc, k_scale_stat_upd, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, mode, dc2.p, cap_c);
+                const int br = ceil_div(M * gr, kBlock), bc = ceil_div(n_lp * gc, kBlock);
+                hipLaunchKernelGGL(k_scale_stat_upd_both, dim3((unsigned)(br + bc)), dim3(kBlock), 0, stream, M, lp_rowptr.p, lp_col.p, Wval(), n_lp,
+                                   c_ptr.p, c_row.p, c_val.p, dr.p, dc.p, mode, dr2.p, dc2.p, cap_c, gr, gc, br);
                 dr.swap(dr2); dc.swap(dc2);
                 continue;
             }
@@ -339,13 +340,13 @@ void Engine::launch_x(const SpMat& AT, double tau, double w, double rho, bool up
             LAUNCH_GB(grp_cols, k_pdhg_x, true, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
         }
     } else {
-        LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xbar.p, ch.p, lh.p, uh.p, tau, w, rho);
+        LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, (double*)nullptr, ch.p, lh.p, uh.p, tau, w, rho);
     }
 }
 
 // Check iteration: the PDHG step without update (xt, yt stored) and the KKT / fixed-point sums.  The row side rides on the
 // y-step (k_pdhg_y_chk gathers xt and x anyway); the column side needs A'yt and is one G-lanes-per-column pass.
-void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double sigma) {
+bool Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double sigma, double w_next, double rho) {
     const int64_t n = n_lp, m = M;
     const int64_t thr = n_long > 0 ? kLongRow : (int64_t)1 << 62;
     const int64_t brow = ceil_div(std::max<int64_t>(m, 1) * grp_rows, kBlock), bcol = ceil_div(n * grp_cols, kBlock);
@@ -385,11 +386,19 @@ void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double si
             allreduce(chkout.p, 12, 0);
             allreduce(chkout.p + 12, 4, 1);
         }
-        return;
+        return false;
     }
-    launch_x(AT, tau, 0.0, 1.0, false, nullptr, nullptr);
+    // the plain CSR form on one GPU: the two step kernels of the check also leave the Halpern update in xnext / ynext
+    const bool spec = w_next >= 0.0 && m > 0 && !row_sharded() && n_long == 0 && n_longc == 0;
+    if (spec) {
+        xnext.resize((size_t)n, stream); ynext.resize((size_t)m, stream);
+        LAUNCH_GB(grp_cols, k_pdhg_x, false, n, stream, n, AT, yh.p, xh.p, x0h.p, xth.p, xnext.p, ch.p, lh.p, uh.p, tau, w_next, rho);
+    } else {
+        launch_x(AT, tau, 0.0, 1.0, false, nullptr, nullptr);
+    }
     if (m > 0) {
-        LAUNCH_G(grp_rows, k_pdhg_y_chk, m, stream, m, A, xth.p, xh.p, yh.p, y0h.p, yth.p, loh.p, hih.p, dr.p, sigma, thr, prow);
+        LAUNCH_G(grp_rows, k_pdhg_y_chk, m, stream, m, A, xth.p, xh.p, yh.p, y0h.p, yth.p, loh.p, hih.p, dr.p, sigma, thr, prow,
+                 spec ? ynext.p : (double*)nullptr, w_next, rho);
         if (n_long > 0)
             hipLaunchKernelGGL((k_pdhg_y_long<true>), dim3((unsigned)n_long), dim3(kLongBlock), 0, stream, d_longrows.p, A, xth.p, xh.p,
                                yh.p, y0h.p, yth.p, loh.p, hih.p, dr.p, sigma, 0.0, 1.0, prow + (size_t)brow * kChkQ);
@@ -410,6 +419,7 @@ void Engine::launch_check(const SpMat& A, const SpMat& AT, double tau, double si
         allreduce(chkout.p, 12, 0);
         allreduce(chkout.p + 12, 4, 1);
     }
+    return spec;
 }
 
 // LP dispatch.  The first-order method is the default: on the large sparse LPs of the hot path it is the only
@@ -923,7 +933,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             continue;
         }
         // ---- check iteration: PDHG step without update, KKT + fixed-point residual
-        launch_check(A, AT, tau, sigma);
+        const bool spec_next = launch_check(A, AT, tau, sigma, (double)(k + 1) / (double)(k + 2), rho);
         check_launch();
         double q[2 * kChkQ];
         if (chk_pinned()) {
@@ -1111,8 +1121,12 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             ++it;
             continue;
         }
-        const double w = (double)(k + 1) / (double)(k + 2);
-        LAUNCH_1(k_halpern2, std::max(n, m), stream, n, m, xh.p, xth.p, x0h.p, yh.p, yth.p, y0h.p, w, rho);
+        if (spec_next) {                                  // the check kernels left the update in xnext / ynext
+            xh.swap(xnext); yh.swap(ynext);
+        } else {
+            const double w = (double)(k + 1) / (double)(k + 2);
+            LAUNCH_1(k_halpern2, std::max(n, m), stream, n, m, xh.p, xth.p, x0h.p, yh.p, yth.p, y0h.p, w, rho);
+        }
         ++k; ++it;
         plain_next = true;       // (after a restart k == 0 and the next pass is a check again: it needs r0)
     }
