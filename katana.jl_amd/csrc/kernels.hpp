@@ -2268,6 +2268,45 @@ static __global__ __launch_bounds__(kBlock) void k_dot_partial(int64_t n, const 
         partials[blockIdx.x] = v;
     }
 }
+// The four sums every LP solve needs before its first step -- ||A^||_F^2, ||c^||^2 and the finite parts of ||lo^||^2, ||hi^||^2 -- in ONE
+// launch (+ one final): partials[q * gridDim + b].  Each sum runs over its array exactly as k_dot_partial / k_finite_sq_partial
+// would (same grid, same stride, same reduction shape): the same bits, six launches less per solve.
+static __global__ __launch_bounds__(kBlock) void k_setup_norms_partial(int64_t nnz, const double* __restrict__ aval, int64_t n,
+                                                                const double* __restrict__ c, int64_t m, const double* __restrict__ lo,
+                                                                const double* __restrict__ hi, double* __restrict__ partials) {
+    const int64_t t0 = (int64_t)blockIdx.x * kBlock + threadIdx.x, stride = (int64_t)gridDim.x * kBlock;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = t0; i < nnz; i += stride) acc[0] += aval[i] * aval[i];
+    for (int64_t i = t0; i < n; i += stride) acc[1] += c[i] * c[i];
+    for (int64_t i = t0; i < m; i += stride) { const double v = lo[i]; if (isfinite(v)) acc[2] += v * v; }
+    for (int64_t i = t0; i < m; i += stride) { const double v = hi[i]; if (isfinite(v)) acc[3] += v * v; }
+    __shared__ double sh[4][kBlock / 64];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double v = group_sum<64>(acc[q]);
+        if ((threadIdx.x & 63) == 0) sh[q][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double v = 0.0;
+        for (int k = 0; k < kBlock / 64; ++k) v += sh[threadIdx.x][k];
+        partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
+    }
+}
+// block q: out[q] = sum of partials[q * nblocks .. ), in the order of k_sum_final
+static __global__ __launch_bounds__(kRedBlocks) void k_sum_final_multi(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+    __shared__ double sh[kRedBlocks / 64];
+    const double* p = partials + (int64_t)blockIdx.x * nblocks;
+    double v = ((int)threadIdx.x < nblocks) ? p[threadIdx.x] : 0.0;
+    v = group_sum<64>(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < kRedBlocks / 64; ++k) t += sh[k];
+        out[blockIdx.x] = t;
+    }
+}
 // partials[b] = sum of log|a_i| (and |b_i|, b optional) over the finite non-zero entries, partials[gridDim + b] = their count:
 // a magnitude statistic that a handful of outliers cannot move (see Engine::lp_solve_core, the initial primal weight)
 static __global__ __launch_bounds__(kBlock) void k_logabs_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ b,

@@ -802,14 +802,9 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     // are all queued into slots behind chkout's check sums and come back with ONE copy and ONE host synchronisation (they
     // were five round trips, each idling the GPU for ~30 us).
     double* slots = chkout.p + 2 * kChkQ;           // [1] power, [2] fro2, [3] nc2, [4] |lo|^2, [5] |hi|^2
-    auto reduce_into = [&](bool finite_sq, int64_t cnt, const double* a, int slot) {
-        if (finite_sq) hipLaunchKernelGGL(k_finite_sq_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, cnt, a, partials.p);
-        else hipLaunchKernelGGL(k_dot_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, cnt, a, a, partials.p);
-        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, slots + slot);
-    };
-    if (NNZ > 0) reduce_into(false, NNZ, r_sval.p, 2);
-    reduce_into(false, n, ch.p, 3);
-    if (m > 0) { reduce_into(true, m, loh.p, 4); reduce_into(true, m, hih.p, 5); }
+    // slots 2..5 (||A^||_F^2, ||c^||^2, finite ||lo^||^2, ||hi^||^2) by one fused pair of launches
+    hipLaunchKernelGGL(k_setup_norms_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, NNZ, r_sval.p, n, ch.p, m, loh.p, hih.p, partials.p);
+    hipLaunchKernelGGL(k_sum_final_multi, dim3(4), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, slots + 2);
     if (w_shift) {                                      // ||c|| of the STORED cost vector: the scale of the (unscaled) dual-residual tolerance
         hipLaunchKernelGGL(k_dot_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, lp_c.p, lp_c.p, partials.p);
         hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, slots + 6);
