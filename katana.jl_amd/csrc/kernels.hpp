@@ -1195,6 +1195,27 @@ static __global__ __launch_bounds__(kBlock) void k_pack_rows(int64_t m, const in
     RowRec r; r.lo = lo[i]; r.hi = hi[i]; r.y0 = yv; r.beg = (int32_t)ptr[i]; r.len = (int32_t)(ptr[i + 1] - ptr[i]);
     rec[i] = r;
 }
+// the packed records of the columns and of the rows in one launch (the bodies of k_pack_cols / k_pack_rows)
+static __global__ __launch_bounds__(kBlock) void k_pack_both(int64_t n, const int64_t* __restrict__ cptr, const double* __restrict__ c,
+                                                      const double* __restrict__ l, const double* __restrict__ u, const double* __restrict__ x,
+                                                      double* __restrict__ x0, ColRec* __restrict__ crec, int2* __restrict__ bl, int64_t m,
+                                                      const int64_t* __restrict__ rptr, const double* __restrict__ lo, const double* __restrict__ hi,
+                                                      const double* __restrict__ y, double* __restrict__ y0, RowRec* __restrict__ rrec) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        const double xv = x[i];
+        x0[i] = xv;
+        ColRec r; r.c = c[i]; r.l = l[i]; r.u = u[i]; r.x0 = xv;
+        crec[i] = r;
+        bl[i] = make_int2((int)cptr[i], (int)(cptr[i + 1] - cptr[i]));
+    }
+    if (i < m) {
+        const double yv = y[i];
+        y0[i] = yv;
+        RowRec r; r.lo = lo[i]; r.hi = hi[i]; r.y0 = yv; r.beg = (int32_t)rptr[i]; r.len = (int32_t)(rptr[i + 1] - rptr[i]);
+        rrec[i] = r;
+    }
+}
 // T outputs per lane group (output g, g + groups, ...): the records and the first entries of all T are requested before any
 // is used, so a wavefront keeps T times the loads in flight and the grid is T times smaller (shorter ramp-up and drain of
 // a ~6 us kernel whose boundary costs ~1.5 us).
@@ -2162,43 +2183,62 @@ __global__ __launch_bounds__(kBlock) void k_scale_vals(int64_t m, const int64_t*
 // scaled problem vectors
 //   mode 0 (LP):        ch = s c dc,  lh = l/dc, uh = u/dc, xh = clip(x/dc)
 //   mode 1 (recession): ch = s c dc,  box = finite? 0 : -+scale_j  (oracle/lp.py recession_ray)
+struct PrepCols { int64_t n; const double *c, *l, *u, *dc, *x, *box; double sgn; int mode; double *ch, *lh, *uh, *xh; };
+struct PrepRows { int64_t m; const double *lo, *hi, *dr, *y; int mode; double *loh, *hih, *yh; };
+__device__ __forceinline__ void prep_col(int64_t j, const PrepCols& a) {
+    if (j >= a.n) return;
+    const double d = a.dc[j];
+    a.ch[j] = a.sgn * a.c[j] * d;
+    double lo = a.l[j], hi = a.u[j];
+    if (a.mode == 1) {
+        const double b = a.box ? a.box[j] : 1.0;
+        lo = isfinite(lo) ? 0.0 : -b;
+        hi = isfinite(hi) ? 0.0 : b;
+    }
+    a.lh[j] = lo / d;
+    a.uh[j] = hi / d;
+    a.xh[j] = clampd((a.mode == 1 ? 0.0 : a.x[j]) / d, lo / d, hi / d);
+}
+__device__ __forceinline__ void prep_row(int64_t i, const PrepRows& r) {
+    if (i >= r.m) return;
+    double a = r.lo[i], b = r.hi[i];
+    if (a != a) a = -__builtin_inf();   // NaN bound = vacuous side (oracle/lp.py add_rows)
+    if (b != b) b = __builtin_inf();
+    if (r.mode == 1) {
+        a = isfinite(a) ? 0.0 : -__builtin_inf();
+        b = isfinite(b) ? 0.0 : __builtin_inf();
+    }
+    const double d = r.dr[i];
+    r.loh[i] = a * d;
+    r.hih[i] = b * d;
+    r.yh[i] = (r.mode == 1) ? 0.0 : r.y[i] / d;
+}
 static __global__ __launch_bounds__(kBlock) void k_prep_cols(int64_t n, const double* __restrict__ c, const double* __restrict__ l,
                                                       const double* __restrict__ u, const double* __restrict__ dc,
                                                       const double* __restrict__ x, const double* __restrict__ box,
                                                       double sgn, int mode, double* __restrict__ ch,
                                                       double* __restrict__ lh, double* __restrict__ uh,
                                                       double* __restrict__ xh) {
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= n) return;
-    const double d = dc[j];
-    ch[j] = sgn * c[j] * d;
-    double lo = l[j], hi = u[j];
-    if (mode == 1) {
-        const double b = box ? box[j] : 1.0;
-        lo = isfinite(lo) ? 0.0 : -b;
-        hi = isfinite(hi) ? 0.0 : b;
-    }
-    lh[j] = lo / d;
-    uh[j] = hi / d;
-    xh[j] = clampd((mode == 1 ? 0.0 : x[j]) / d, lo / d, hi / d);
+    prep_col((int64_t)blockIdx.x * kBlock + threadIdx.x, PrepCols{n, c, l, u, dc, x, box, sgn, mode, ch, lh, uh, xh});
 }
 static __global__ __launch_bounds__(kBlock) void k_prep_rows(int64_t m, const double* __restrict__ lo, const double* __restrict__ hi,
                                                       const double* __restrict__ dr, const double* __restrict__ y, int mode,
                                                       double* __restrict__ loh, double* __restrict__ hih,
                                                       double* __restrict__ yh) {
+    prep_row((int64_t)blockIdx.x * kBlock + threadIdx.x, PrepRows{m, lo, hi, dr, y, mode, loh, hih, yh});
+}
+// columns and rows of a solve's start in one launch (thread i takes column i and row i)
+static __global__ __launch_bounds__(kBlock) void k_prep_both(PrepCols C, PrepRows R) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= m) return;
-    double a = lo[i], b = hi[i];
-    if (a != a) a = -__builtin_inf();   // NaN bound = vacuous side (oracle/lp.py add_rows)
-    if (b != b) b = __builtin_inf();
-    if (mode == 1) {
-        a = isfinite(a) ? 0.0 : -__builtin_inf();
-        b = isfinite(b) ? 0.0 : __builtin_inf();
-    }
-    const double d = dr[i];
-    loh[i] = a * d;
-    hih[i] = b * d;
-    yh[i] = (mode == 1) ? 0.0 : y[i] / d;
+    prep_col(i, C);
+    prep_row(i, R);
+}
+// x = xh . dc and y = yh . dr in one launch
+static __global__ __launch_bounds__(kBlock) void k_unscale2(int64_t n, const double* __restrict__ xh, const double* __restrict__ dc, double* __restrict__ x,
+                                                     int64_t m, const double* __restrict__ yh, const double* __restrict__ dr, double* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) x[i] = xh[i] * dc[i];
+    if (i < m) y[i] = yh[i] * dr[i];
 }
 static __global__ __launch_bounds__(kBlock) void k_unscale(int64_t n, const double* __restrict__ zh, const double* __restrict__ d,
                                                     double* __restrict__ z) {
@@ -2364,6 +2404,26 @@ static __global__ __launch_bounds__(kBlock) void k_normalize(int64_t n, const do
                                                       double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const double s = normsq[0];
+    if (i < n) out[i] = (s > 0.0) ? a[i] / sqrt(s) : 0.0;
+}
+// the same with the second stage of the reduction folded in: every block adds up the kRedBlocks partials of ||a||^2 itself, in the
+// order of k_sum_final (same bits), instead of reading the sum a launch of its own would have left
+static __global__ __launch_bounds__(kRedBlocks) void k_normalize_sum(int64_t n, const double* __restrict__ a, const double* __restrict__ partials,
+                                                              double* __restrict__ out) {
+    __shared__ double sh[kRedBlocks / 64];
+    __shared__ double s_tot;
+    double v = partials[threadIdx.x];
+    v = group_sum<64>(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < kRedBlocks / 64; ++k) t += sh[k];
+        s_tot = t;
+    }
+    __syncthreads();
+    const double s = s_tot;
+    const int64_t i = (int64_t)blockIdx.x * kRedBlocks + threadIdx.x;
     if (i < n) out[i] = (s > 0.0) ? a[i] / sqrt(s) : 0.0;
 }
 static __global__ __launch_bounds__(kBlock) void k_fill(int64_t n, double* __restrict__ z, double v) {

@@ -700,9 +700,9 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     loh.resize(mm, stream); hih.resize(mm, stream); yh.resize(mm, stream); y0h.resize(mm, stream);
     yth.resize(mm, stream); pw.resize(mm, stream);
     const double sgn = (sense == KTN_MAX) ? -1.0 : 1.0;
-    LAUNCH_1(k_prep_cols, n, stream, n, Wc(), lp_l.p, lp_u.p, dc.p, lp_x.p, (mode == 1 ? box.p : (double*)nullptr), sgn,
-             mode, ch.p, lh.p, uh.p, xh.p);
-    LAUNCH_1(k_prep_rows, m, stream, m, Wlo(), Whi(), dr.p, lp_y.p, mode, loh.p, hih.p, yh.p);
+    LAUNCH_1(k_prep_both, std::max(n, m), stream,
+             PrepCols{n, Wc(), lp_l.p, lp_u.p, dc.p, lp_x.p, (mode == 1 ? box.p : (const double*)nullptr), sgn, mode, ch.p, lh.p, uh.p, xh.p},
+             PrepRows{m, Wlo(), Whi(), dr.p, lp_y.p, mode, loh.p, hih.p, yh.p});
     if (w_shift) {                                      // the epigraph variable of the start: s = t - a_ref'x - b_ref
         epi_dot(lp_x.p);
         hipLaunchKernelGGL(k_epi_var, dim3(1), dim3(1), 0, stream, xh.p, (int32_t)n0, epi_scal.p, (const double*)dc.p, -1, have_omega ? 0 : 1, sgn, epi_newest.p);
@@ -771,8 +771,11 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             hipLaunchKernelGGL(k_dot_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, a, a, partials.p);
             hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, out);
         };
-        dot_dev(power_v.p, nrm);
-        LAUNCH_1(k_normalize, n, stream, n, power_v.p, nrm, pv.p);
+        auto normalize_into = [&](const double* a, double* out) {        // out = a / ||a||: partial sums, then k_normalize_sum adds them up itself
+            hipLaunchKernelGGL(k_dot_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, a, a, partials.p);
+            hipLaunchKernelGGL(k_normalize_sum, dim3(ceil_div(n, (int64_t)kRedBlocks)), dim3(kRedBlocks), 0, stream, n, a, partials.p, out);
+        };
+        normalize_into(power_v.p, pv.p);
         const int passes_env = dev.power_passes;
         const int iters = passes_env > 0 ? passes_env : 8;
         // The iterate is re-normalised only every fourth pass (and before the last, whose ||A'A v|| with ||v|| = 1 is the
@@ -789,8 +792,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             if (norm_now) {
                 spmv_cols(AT, pw.p, xbar.p);
                 allreduce(xbar.p, (size_t)n, 0);            // row-sharded: A'A v = sum over the ranks of A_r'(A_r v)
-                dot_dev(xbar.p, nrm);                       // on the last pass: ||A'A v||^2 with ||v|| = 1
-                LAUNCH_1(k_normalize, n, stream, n, xbar.p, nrm, pv.p);
+                if (it == iters - 1) dot_dev(xbar.p, nrm);  // the last pass: ||A'A v||^2 with ||v|| = 1 is the estimate; the vector is not needed again
+                else normalize_into(xbar.p, pv.p);
             } else {
                 spmv_cols(AT, pw.p, pv.p);
                 allreduce(pv.p, (size_t)n, 0);
@@ -869,8 +872,8 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     if (dev.packed_trips > 0) packed_trips = dev.packed_trips;
     if (packed_on) {
         d_crec.resize((size_t)n, stream); d_cbl.resize((size_t)n, stream); d_rrec.resize(mm, stream);
-        LAUNCH_1(k_pack_cols, n, stream, n, c_ptr.p, ch.p, lh.p, uh.p, xh.p, x0h.p, d_crec.p, d_cbl.p);
-        LAUNCH_1(k_pack_rows, m, stream, m, lp_rowptr.p, loh.p, hih.p, yh.p, y0h.p, d_rrec.p);
+        LAUNCH_1(k_pack_both, std::max(n, m), stream, n, c_ptr.p, ch.p, lh.p, uh.p, xh.p, x0h.p, d_crec.p, d_cbl.p,
+                 m, lp_rowptr.p, loh.p, hih.p, yh.p, y0h.p, d_rrec.p);
     } else {
         KTN_HIP(hipMemcpyAsync(x0h.p, xh.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
         if (m > 0) KTN_HIP(hipMemcpyAsync(y0h.p, yh.p, m * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -1128,8 +1131,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     R.iters = it;
     // un-scale the last PDHG point (xt, yt)
     if (mode == 0) {
-        LAUNCH_1(k_unscale, n, stream, n, xth.p, dc.p, lp_x.p);
-        LAUNCH_1(k_unscale, m, stream, m, yth.p, dr.p, lp_y.p);
+        LAUNCH_1(k_unscale2, std::max(n, m), stream, n, xth.p, dc.p, lp_x.p, m, yth.p, dr.p, lp_y.p);
         if (w_shift) {                                  // back to the epigraph variable of the stored LP: t = s + a_ref'x + b_ref
             epi_dot(lp_x.p);
             hipLaunchKernelGGL(k_epi_var, dim3(1), dim3(1), 0, stream, lp_x.p, (int32_t)n0, epi_scal.p, (const double*)nullptr, 1, 0, sgn, epi_newest.p);
