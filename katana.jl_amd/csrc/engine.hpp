@@ -237,7 +237,8 @@ struct Engine {
     int packed_trips = 1;          // outputs per lane group in the packed kernels (KTN_PACKED_TRIPS: 1, 2, 4)
     DBuf<double> dr2, dc2;                      // ping-pong partners of dr / dc in the scaling passes
     DBuf<double> dr, dc, statr, statc, ch, lh, uh, loh, hih, xh, yh, x0h, y0h, xth, yth, xbar, pv, pw, box;
-    DBuf<double> partials, chk_part, chkout, power_v;
+    DBuf<double> partials, chk_part, chkout, power_v, power_v0;
+    int64_t power_v0_n = -1;                   // size the cached start vector of the power iteration was made for
     // the check sums of a one-GPU solve land in pinned, device-mapped host memory: k_chk_final writes them there and the host
     // reads them after the stream synchronisation -- no copy kernel (4.5 us + a boundary) per check
     double* h_chk = nullptr;

@@ -2180,6 +2180,27 @@ __global__ __launch_bounds__(kBlock) void k_scale_vals(int64_t m, const int64_t*
     for (int64_t e = ptr[i] + lane; e < ptr[i + 1]; e += G) sval[e] = di * val[e] * dother[idx[e]];
 }
 
+// the scaled values of the row copy and of the column mirror in one launch (blocks [0, br): rows with gr lanes, the rest: columns)
+static __global__ __launch_bounds__(kBlock) void k_scale_vals_both(int64_t m, const int64_t* __restrict__ rptr, const int32_t* __restrict__ ridx,
+                                                            const double* __restrict__ rval, int64_t n, const int64_t* __restrict__ cptr,
+                                                            const int32_t* __restrict__ cidx, const double* __restrict__ cval,
+                                                            const double* __restrict__ dr, const double* __restrict__ dc,
+                                                            double* __restrict__ rsval, double* __restrict__ csval, int gr, int gc, int br) {
+    const bool rows = (int)blockIdx.x < br;
+    const int g = rows ? gr : gc;
+    const int64_t t = (int64_t)(rows ? blockIdx.x : blockIdx.x - br) * kBlock + threadIdx.x;
+    const int64_t i = t / g;
+    const int lane = (int)(t & (g - 1));
+    if (i >= (rows ? m : n)) return;
+    const int64_t* ptr = rows ? rptr : cptr;
+    const int32_t* idx = rows ? ridx : cidx;
+    const double* val = rows ? rval : cval;
+    const double* dother = rows ? dc : dr;
+    double* sval = rows ? rsval : csval;
+    const double di = rows ? dr[i] : dc[i];
+    for (int64_t e = ptr[i] + lane; e < ptr[i + 1]; e += g) sval[e] = di * val[e] * dother[idx[e]];
+}
+
 // scaled problem vectors
 //   mode 0 (LP):        ch = s c dc,  lh = l/dc, uh = u/dc, xh = clip(x/dc)
 //   mode 1 (recession): ch = s c dc,  box = finite? 0 : -+scale_j  (oracle/lp.py recession_ray)

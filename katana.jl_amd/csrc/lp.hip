@@ -107,10 +107,16 @@ void Engine::compute_scaling(bool identity) {
     scal_cols = n_lp;
     r_sval.resize((size_t)NNZ + 1, stream);
     c_sval.resize((size_t)NNZ + 1, stream);
-    LAUNCH_G(gr, k_scale_vals, M, stream, M, lp_rowptr.p, lp_col.p, Wval(), dr.p, dc.p, r_sval.p);
     // (long columns: the mirror's scaled values are gathered entry-parallel from the row copy instead of walked column by column)
-    if (n_longc > 0) LAUNCH_1(k_csc_vals, NNZ, stream, NNZ, c_perm.p, r_sval.p, c_sval.p);
-    else LAUNCH_G(gc, k_scale_vals, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, c_sval.p);
+    if (n_longc > 0 || M == 0) {
+        LAUNCH_G(gr, k_scale_vals, M, stream, M, lp_rowptr.p, lp_col.p, Wval(), dr.p, dc.p, r_sval.p);
+        if (n_longc > 0) LAUNCH_1(k_csc_vals, NNZ, stream, NNZ, c_perm.p, r_sval.p, c_sval.p);
+        else LAUNCH_G(gc, k_scale_vals, n_lp, stream, n_lp, c_ptr.p, c_row.p, c_val.p, dc.p, dr.p, c_sval.p);
+    } else {                                            // both copies in one launch
+        const int br = ceil_div(M * gr, kBlock), bc = ceil_div(n_lp * gc, kBlock);
+        hipLaunchKernelGGL(k_scale_vals_both, dim3((unsigned)(br + bc)), dim3(kBlock), 0, stream, M, lp_rowptr.p, lp_col.p, Wval(), n_lp, c_ptr.p, c_row.p,
+                           c_val.p, dr.p, dc.p, r_sval.p, c_sval.p, gr, gc, br);
+    }
     check_launch();
 }
 
@@ -764,9 +770,7 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         // the estimate tighter and the step therefore smaller -- cfg3 then needs 14 700 instead of 7 800 PDHG
         // iterations; boosting eta by 5 % over the tight estimate stalls the method.  The slightly generous
         // cold estimate plus the back-off safeguard is the better operating point.)
-        double* nrm = chkout.p + 2 * kChkQ + 1;
-        power_v.resize(n, stream);
-        LAUNCH_1(k_hash_fill, n, stream, n, power_v.p);
+        double* nrm = (chk_pinned() ? h_chk_dev : chkout.p) + 2 * kChkQ + 1;
         auto dot_dev = [&](const double* a, double* out) {
             hipLaunchKernelGGL(k_dot_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, a, a, partials.p);
             hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, out);
@@ -775,18 +779,25 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
             hipLaunchKernelGGL(k_dot_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, n, a, a, partials.p);
             hipLaunchKernelGGL(k_normalize_sum, dim3(ceil_div(n, (int64_t)kRedBlocks)), dim3(kRedBlocks), 0, stream, n, a, partials.p, out);
         };
-        normalize_into(power_v.p, pv.p);
+        // the start vector -- hashed, normalised -- depends on n alone: made once per handle (and size), read by the first pass in place
+        if (power_v0_n != n) {
+            power_v.resize(n, stream); power_v0.resize(n, stream);
+            LAUNCH_1(k_hash_fill, n, stream, n, power_v.p);
+            normalize_into(power_v.p, power_v0.p);
+            power_v0_n = n;
+        }
         const int passes_env = dev.power_passes;
         const int iters = passes_env > 0 ? passes_env : 8;
         // The iterate is re-normalised only every fourth pass (and before the last, whose ||A'A v|| with ||v|| = 1 is the
         // estimate): with ||A^||_2 <= 1 after the Pock-Chambolle pass the un-normalised vector only shrinks slowly, and the
         // Rayleigh quotient does not depend on the scale -- 6 instead of 20 (dot, final sum, normalise) triples per LP solve.
         for (int it = 0; it < iters; ++it) {
+            const double* vin = (it == 0) ? power_v0.p : pv.p;
             if (n_long > 0) {
-                LAUNCH_G(grp_rows, k_spmv_skip, m, stream, m, A, pv.p, pw.p, kLongRow);
-                hipLaunchKernelGGL(k_spmv_long, dim3((unsigned)n_long), dim3(1024), 0, stream, d_longrows.p, A, pv.p, pw.p);
+                LAUNCH_G(grp_rows, k_spmv_skip, m, stream, m, A, vin, pw.p, kLongRow);
+                hipLaunchKernelGGL(k_spmv_long, dim3((unsigned)n_long), dim3(1024), 0, stream, d_longrows.p, A, vin, pw.p);
             } else {
-                LAUNCH_G(grp_rows, k_spmv, m, stream, m, A, pv.p, pw.p);
+                LAUNCH_G(grp_rows, k_spmv, m, stream, m, A, vin, pw.p);
             }
             const bool norm_now = (it % 4 == 3) || it >= iters - 2;
             if (norm_now) {
@@ -804,7 +815,10 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
     // The scalars the loop needs -- the power iteration's ||A'A v||, ||A^||_F^2, ||c^||^2 and the finite parts of ||lo^||^2, ||hi^||^2 --
     // are all queued into slots behind chkout's check sums and come back with ONE copy and ONE host synchronisation (they
     // were five round trips, each idling the GPU for ~30 us).
-    double* slots = chkout.p + 2 * kChkQ;           // [1] power, [2] fro2, [3] nc2, [4] |lo|^2, [5] |hi|^2
+    // (one-GPU solves: the final sums are written straight into the pinned, device-mapped block the check sums use -- no copy kernel,
+    //  the host reads them after the synchronisation)
+    const bool pin_slots = chk_pinned();
+    double* slots = (pin_slots ? h_chk_dev : chkout.p) + 2 * kChkQ;           // [1] power, [2] fro2, [3] nc2, [4] |lo|^2, [5] |hi|^2
     // slots 2..5 (||A^||_F^2, ||c^||^2, finite ||lo^||^2, ||hi^||^2) by one fused pair of launches
     hipLaunchKernelGGL(k_setup_norms_partial, dim3(kRedBlocks), dim3(kBlock), 0, stream, NNZ, r_sval.p, n, ch.p, m, loh.p, hih.p, partials.p);
     hipLaunchKernelGGL(k_sum_final_multi, dim3(4), dim3(kRedBlocks), 0, stream, partials.p, kRedBlocks, slots + 2);
@@ -829,10 +843,11 @@ LpResult Engine::lp_solve_core(double tol_p, double tol_g, int mode, bool identi
         logstat(m, loh.p, hih.p, 10);
     }
     double hs[12] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    KTN_HIP(hipMemcpyAsync(hs, slots, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    if (!pin_slots) KTN_HIP(hipMemcpyAsync(hs, slots, sizeof(hs), hipMemcpyDeviceToHost, stream));
     double epi_b = 0.0;                                 // b_ref of the working form: the objective constant it carries
     if (w_shift) KTN_HIP(hipMemcpyAsync(&epi_b, epi_scal.p, sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
+    if (pin_slots) std::memcpy(hs, h_chk + 2 * kChkQ, sizeof(hs));
     const double obj_shift = sgn * epi_b;               // internal objective of the stored LP = working objective + obj_shift
     if (have_power) {
         const double nv2 = hs[1];
