@@ -92,6 +92,37 @@ def test_product_never_imports_the_oracle():
     assert out == "False"
 
 
+def test_abi_layer_does_not_depend_on_the_kernel_headers():
+    """csrc/abi.hip launches no kernel: it includes engine.hpp only, and engine.hpp none of the kernel headers -- so that a change to
+    a kernel rebuilds the units that launch kernels and leaves the ABI layer alone (csrc/Makefile: _build/abi.o on HOST_HDRS)."""
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "katana.jl_amd", "csrc")
+    kernel_hdrs = {"kernels.hpp", "dense_lp.hpp", "mid_lp.hpp", "batch_lp.hpp", "batch_ecp.hpp", "launch.hpp"}
+
+    def includes(name, seen):
+        for inc in re.findall(r'^#include "([^"]+)"', open(os.path.join(csrc, name)).read(), re.M):
+            inc = os.path.basename(inc)
+            if inc not in seen and os.path.exists(os.path.join(csrc, inc)):
+                seen.add(inc)
+                includes(inc, seen)
+        return seen
+    reach = includes("abi.hip", set())
+    assert "engine.hpp" in reach and not (reach & kernel_hdrs), reach
+    text = open(os.path.join(csrc, "abi.hip")).read()
+    assert "hipLaunchKernelGGL" not in text and "LAUNCH_" not in text
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert re.search(r"^_build/abi\.o: abi\.hip \$\(HOST_HDRS\)$", mk, re.M)
+    # ... and the units that do launch kernels share the headers safely: no non-template kernel with external linkage
+    for h in sorted(kernel_hdrs - {"launch.hpp"}):
+        lines = open(os.path.join(csrc, h)).read().split("\n")
+        for i, ln in enumerate(lines):
+            if ln.startswith("__global__ "):
+                j = i - 1
+                while j >= 0 and not lines[j].strip():
+                    j -= 1
+                assert lines[j].lstrip().startswith("template"), "%s:%d: a non-template kernel in a shared header must be static" % (h, i + 1)
+
+
 def test_unknown_feature_and_option_are_errors(ktn):
     with pytest.raises(ValueError):
         ktn.KatanaSolver(features=["NoSuchFeature"])          # setfield! on KatanaFeatures, src/model.jl:50-52
